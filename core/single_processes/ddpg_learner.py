@@ -1,0 +1,3 @@
+"""Alias of pytorch_distributed_amd.agents.learners (reference import path core/single_processes/ddpg_learner.py)."""
+from pytorch_distributed_amd.agents.learners import *  # noqa: F401,F403
+from pytorch_distributed_amd.agents.learners import ddpg_learner  # noqa: F401

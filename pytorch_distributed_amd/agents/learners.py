@@ -1,0 +1,220 @@
+"""Learner processes (reference core/single_processes/dqn_learner.py:9-103 and
+ddpg_learner.py:9-108; same signatures).
+
+What changed relative to the reference:
+* each learner owns its model on its own device and is one rank of a
+  synchronous data-parallel group (flat-gradient all-reduce, parallel/comm.py)
+  instead of a Hogwild writer on one shared CUDA model;
+* rank 0 publishes weights to the shared `global_model` every
+  `param_sync_freq` steps (utils/param_store.py);
+* prioritized replay is live: importance-weighted loss and |TD| write-back;
+* two step back-ends: "torch" (fp32 eager; CPU plumbing and the oracle) and
+  "native" (ops/dqn_engine.py, ops/ddpg_engine.py: HIP kernels, bf16 MFMA,
+  HBM replay, one captured graph per step) picked by `args.compute`.
+
+`DqnTorchCore` / `DdpgTorchCore` hold the per-step arithmetic so tests and the
+benchmark can drive it without processes.
+"""
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..parallel.comm import SingleComm, make_comm
+from ..utils.helpers import update_target_model
+from ..utils.param_store import publish_params, sync_params
+
+
+def _clip_value_(params, clip):
+    if clip is None or not np.isfinite(clip):
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if grads:
+        torch._foreach_clamp_min_(grads, -float(clip))
+        torch._foreach_clamp_max_(grads, float(clip))
+
+
+class _TorchCore(object):
+    def __init__(self, args, model, target_model, memory, comm=None):
+        self.args, self.ap = args, args.agent_params
+        self.model, self.target_model, self.memory = model, target_model, memory
+        self.comm = comm or SingleComm()
+        self.device = next(model.parameters()).device
+        update_target_model(model, target_model)      # hard copy to start
+        self.model.flatten_()
+        self.optimizer = self.ap.optim(self.model.parameters(), lr=self.ap.lr,
+                                       weight_decay=self.ap.weight_decay)
+        self.model.train()
+        self.step_count = 0
+        self.last_losses = {}
+
+    def _batch(self):
+        batch, inds, weights = self.memory.sample_with_priorities(self.ap.batch_size)
+        s0, a, r, g, s1, t = (x.to(self.device, non_blocking=True) for x in batch)
+        return s0, a, r, g, s1, t, inds, weights.to(self.device)
+
+    def _weighted_mse(self, pred, target, weights):
+        if self.memory.enable_per:
+            return (weights * (pred - target) ** 2).mean()
+        return self.ap.value_criteria(pred, target)
+
+    def _finish(self, td_abs, inds):
+        if self.comm.world_size > 1:
+            self.comm.all_reduce_mean_(self.model.flat_grads)
+        self.optimizer.step()
+        update_target_model(self.model, self.target_model, self.ap.target_model_update, self.step_count)
+        if self.memory.enable_per:
+            self.memory.update_priorities(inds, td_abs)
+        self.step_count += 1
+
+    def flat_params(self):
+        return self.model.flat_params
+
+    def loss_values(self):
+        return {k: float(v) for k, v in self.last_losses.items()}
+
+
+class DqnTorchCore(_TorchCore):
+    def step(self):
+        s0, a, r, g, s1, t, inds, w = self._batch()
+        self.model.zero_flat_grad()
+        with torch.no_grad():
+            if self.ap.enable_double:
+                next_a = self.model(s1).argmax(dim=1, keepdim=True)
+                next_q = self.target_model(s1).gather(1, next_a)
+            else:
+                next_q = self.target_model(s1).max(dim=1, keepdim=True)[0]
+            target = r + g * next_q * (1 - t)
+        pred = self.model(s0).gather(1, a.long())
+        loss = self._weighted_mse(pred, target, w)
+        loss.backward()
+        _clip_value_(self.model.critic.parameters(), self.ap.clip_grad)
+        self.last_losses = {"critic_loss": loss.detach()}
+        self._finish((pred.detach() - target).abs(), inds)
+
+
+class DdpgTorchCore(_TorchCore):
+    def step(self):
+        s0, a, r, g, s1, t, inds, w = self._batch()
+        self.model.zero_flat_grad()
+        leak = getattr(self.ap, "compat_ddpg_grad_leak", True)
+        # actor loss: -Q(s, pi(s)).  The reference lets this backward also leave
+        # gradients in the critic, which then add to the critic loss gradients.
+        if not leak:
+            for p in self.model.critic.parameters():
+                p.requires_grad_(False)
+        _, q_pi = self.model(s0)
+        actor_loss = -q_pi.mean()
+        actor_loss.backward()
+        if not leak:
+            for p in self.model.critic.parameters():
+                p.requires_grad_(True)
+        _clip_value_(self.model.actor.parameters(), self.ap.clip_grad)
+        with torch.no_grad():
+            _, next_q = self.target_model(s1)
+            target = r + g * next_q * (1 - t)
+        pred = self.model.forward_critic(s0, a)
+        critic_loss = self._weighted_mse(pred, target, w)
+        critic_loss.backward()
+        _clip_value_(self.model.critic.parameters(), self.ap.clip_grad)
+        self.last_losses = {"actor_loss": actor_loss.detach(), "critic_loss": critic_loss.detach()}
+        self._finish((pred.detach() - target).abs(), inds)
+
+
+def _pick_compute(args, device):
+    mode = getattr(args, "compute", "auto")
+    if mode == "torch" or device.type != "cuda":
+        return "torch"
+    from .. import ops
+    if ops.native_available():
+        return "native"
+    if mode == "native":
+        raise RuntimeError("compute='native' requested but the HIP extension is not loadable: " + ops.native_error())
+    return "torch"
+
+
+def make_core(kind, args, model, target_model, memory, comm, device):
+    compute = _pick_compute(args, device)
+    if compute == "native":
+        if kind == "dqn" and args.model_type == "dqn-cnn":
+            from ..ops.dqn_engine import DqnNativeCore
+            return DqnNativeCore(args, model, target_model, memory, comm)
+        if args.model_type in ("ddpg-mlp", "dqn-mlp"):
+            from ..ops.mlp_engine import make_mlp_native_core
+            core = make_mlp_native_core(kind, args, model, target_model, memory, comm)
+            if core is not None:
+                return core
+    return (DqnTorchCore if kind == "dqn" else DdpgTorchCore)(args, model, target_model, memory, comm)
+
+
+def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
+                  global_memory, global_model, global_optimizer, kind):
+    print("---------------------------->", process_ind, "learner")
+    ap = args.agent_params
+    rank = process_ind - args.num_actors - 1
+    world = args.num_learners
+    if args.device == "cuda":
+        ngpu = torch.cuda.device_count()
+        local_device = torch.device("cuda:%d" % ((args.gpu_ind + rank) % max(ngpu, 1)))
+        torch.cuda.set_device(local_device)
+    else:
+        local_device = torch.device("cpu")
+        torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
+    torch.manual_seed(args.seed + 1000 * rank)
+    np.random.seed(args.seed + 1000 * rank)
+
+    comm = make_comm(rank, world, local_device, port=getattr(args, "dist_port", None))
+
+    def build():
+        return model_prototype(args.model_params, args.norm_val, args.state_shape,
+                               args.action_space, args.action_shape).to(local_device)
+    local_model, local_target_model = build(), build()
+    sync_params(local_model, global_model)
+    if world > 1:       # all ranks start from rank 0's weights
+        comm.broadcast_(local_model.flatten_(), src=0)
+
+    if hasattr(global_memory, "attach"):    # device replay: allocate this rank's HBM shard
+        global_memory.attach(local_device, rank=rank, world_size=world)
+
+    torch.set_grad_enabled(True)
+    core = make_core(kind, args, local_model, local_target_model, global_memory, comm, local_device)
+
+    step = 0
+    started = False
+    while step < ap.steps and not global_logs.stop.value:
+        if hasattr(global_memory, "drain"):
+            global_logs.frames_ingested.value += global_memory.drain()
+        if not started:
+            ready = global_memory.size > ap.learn_start
+            started = comm.all_agree(ready)
+            if not started:
+                time.sleep(0.05 if hasattr(global_memory, "drain") else 1.0)
+                continue
+        core.step()
+        step += 1
+        if rank == 0:
+            with global_logs.learner_step.get_lock():
+                global_logs.learner_step.value += 1
+            if step % args.param_sync_freq == 0 or step == ap.steps:
+                publish_params(global_model, core.flat_params())
+            if step % ap.learner_freq == 0:
+                for name, val in core.loss_values().items():
+                    getattr(learner_logs, name).value += val
+                learner_logs.loss_counter.value += 1
+                global_logs.beat("learner")
+    if rank == 0:
+        publish_params(global_model, core.flat_params())
+    comm.close()
+
+
+def dqn_learner(process_ind, args, global_logs, learner_logs, model_prototype,
+                global_memory, global_model, global_optimizer=None):
+    _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
+                  global_memory, global_model, global_optimizer, "dqn")
+
+
+def ddpg_learner(process_ind, args, global_logs, learner_logs, model_prototype,
+                 global_memory, global_model, global_optimizer=None):
+    _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
+                  global_memory, global_model, global_optimizer, "ddpg")

@@ -1,0 +1,84 @@
+"""n-step transition assembly with the reference actors' exact bookkeeping
+(core/single_processes/dqn_actor.py:55-61,110-163):
+
+* windows hold nstep+2 states and nstep+1 actions/rewards/terminals;
+* once three states are buffered, every step emits the *lagged* transition
+  (s[0], a[0], sum_{i<len(r)-1} gamma^i r_i, gamma^(len(s)-2), s[-2], t[-2]) --
+  one step late so that max_a Q(s[-2]) is known for the initial priority;
+* when the episode ends exactly one more transition is emitted, reaching the
+  true last state: from s[1] if the window is full, else from s[0];
+* windows never straddle episodes;
+* with PER the initial priority is |R + gamma^k max_a Q(s_k) - Q(s0, a0)| using
+  the actor's own (stale) network.
+
+`nstep_batch_returns` is the vectorised form used by the device-side actor pool.
+"""
+from collections import deque
+
+import numpy as np
+
+
+class NStepAssembler(object):
+    def __init__(self, nstep, gamma, enable_per=False):
+        self.nstep = int(nstep)
+        self.gamma = float(gamma)
+        self.enable_per = bool(enable_per)
+        self.states = deque(maxlen=self.nstep + 2)
+        self.actions = deque(maxlen=self.nstep + 1)
+        self.rewards = deque(maxlen=self.nstep + 1)
+        self.terminals = deque(maxlen=self.nstep + 1)
+        self.qvalues = deque(maxlen=self.nstep + 1)
+        self.max_qvalues = deque(maxlen=self.nstep + 1)
+
+    def reset(self, state):
+        for d in (self.states, self.actions, self.rewards, self.terminals, self.qvalues, self.max_qvalues):
+            d.clear()
+        self.states.append(state)
+
+    def _ret(self, start, stop, shift):
+        return float(sum(self.rewards[i] * self.gamma ** (i - shift) for i in range(start, stop)))
+
+    def _priority(self, ret, gamma_sn, max_q, q0):
+        if not self.enable_per or max_q is None or q0 is None:
+            return 0.0
+        return abs(ret + gamma_sn * max_q - q0)
+
+    def push(self, action, reward, state1, terminal1, qvalue=None, max_qvalue=None):
+        """Record one env step; returns [(transition, priority)] (0 or 1 items)."""
+        self.states.append(state1)
+        self.actions.append(action)
+        self.rewards.append(reward)
+        self.terminals.append(terminal1)
+        self.qvalues.append(qvalue)
+        self.max_qvalues.append(max_qvalue)
+        if len(self.states) < 3:
+            return []
+        ret = self._ret(0, len(self.rewards) - 1, 0)
+        gamma_sn = self.gamma ** (len(self.states) - 2)
+        prio = self._priority(ret, gamma_sn, self.max_qvalues[-1], self.qvalues[0])
+        return [((self.states[0], self.actions[0], [ret], [gamma_sn],
+                  self.states[-2], self.terminals[-2]), prio)]
+
+    def flush(self, max_qvalue_last=None):
+        """Episode ended: emit the one closing transition."""
+        if not self.actions:
+            return []
+        if len(self.states) >= self.nstep + 2:
+            first = 1
+            ret = self._ret(1, len(self.rewards), 1)
+            gamma_sn = self.gamma ** (len(self.states) - 2)
+        else:
+            first = 0
+            ret = self._ret(0, len(self.rewards), 0)
+            gamma_sn = self.gamma ** (len(self.states) - 1)
+        prio = self._priority(ret, gamma_sn, max_qvalue_last, self.qvalues[first])
+        return [((self.states[first], self.actions[first], [ret], [gamma_sn],
+                  self.states[-1], self.terminals[-1]), prio)]
+
+
+def nstep_batch_returns(rewards, gamma):
+    """rewards (..., k) -> discounted sums (...,) and gamma^k."""
+    rewards = np.asarray(rewards, dtype=np.float64)
+    k = rewards.shape[-1]
+    disc = gamma ** np.arange(k)
+    return (rewards * disc).sum(-1), gamma ** k

@@ -1,0 +1,162 @@
+"""Atari via ALE with the DeepMind-style preprocessing the reference uses
+(core/envs/atari_env.py:19-129): grayscale -> 84x84 bilinear, 4-frame stack,
+action repeat 4 with a max over the last two frames, up to 30 no-op starts,
+loss-of-life terminals in training mode only, sticky actions off, episode cap
+`early_stop`.
+
+ALE (`ale_py` or `atari_py`) and OpenCV are optional imports: the class raises
+a clear ImportError when no backend is present, and `make_atari_env` (what the
+factory registers) then falls back to SyntheticAtariEnv with a warning so that
+`python main.py` stays runnable on a box without ROMs.
+"""
+import warnings
+from collections import deque
+
+import numpy as np
+
+from .env import Env
+
+
+def _find_ale():
+    try:
+        import ale_py  # noqa: F401
+        return "ale_py"
+    except Exception:
+        pass
+    try:
+        import atari_py  # noqa: F401
+        return "atari_py"
+    except Exception:
+        return None
+
+
+def resize_bilinear_u8(img, out_h, out_w):
+    """Bilinear resize matching cv2.INTER_LINEAR's half-pixel sampling; used
+    when OpenCV is not installed."""
+    try:
+        import cv2
+        return cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_LINEAR)
+    except Exception:
+        pass
+    in_h, in_w = img.shape[:2]
+    ys = np.clip((np.arange(out_h) + 0.5) * in_h / out_h - 0.5, 0, in_h - 1)
+    xs = np.clip((np.arange(out_w) + 0.5) * in_w / out_w - 0.5, 0, in_w - 1)
+    y0, x0 = np.floor(ys).astype(np.int64), np.floor(xs).astype(np.int64)
+    y1, x1 = np.minimum(y0 + 1, in_h - 1), np.minimum(x0 + 1, in_w - 1)
+    wy, wx = (ys - y0)[:, None], (xs - x0)[None, :]
+    f = img.astype(np.float32)
+    top = f[y0][:, x0] * (1 - wx) + f[y0][:, x1] * wx
+    bot = f[y1][:, x0] * (1 - wx) + f[y1][:, x1] * wx
+    return np.clip(np.rint(top * (1 - wy) + bot * wy), 0, 255).astype(np.uint8)
+
+
+class AtariEnv(Env):
+    def __init__(self, args, process_ind=0, num_envs_per_process=1):
+        super().__init__(args, process_ind, num_envs_per_process)
+        assert self.num_envs_per_process == 1
+        backend = _find_ale()
+        if backend is None:
+            raise ImportError("AtariEnv needs ale_py or atari_py; neither is installed")
+        if backend == "atari_py":
+            import atari_py
+            self.ale = atari_py.ALEInterface()
+            rom = atari_py.get_game_path(self.game)
+        else:
+            import ale_py
+            self.ale = ale_py.ALEInterface()
+            import ale_py.roms as roms
+            rom = getattr(roms, self.game.capitalize())
+        self.ale.setInt("random_seed", self.seed)
+        self.ale.setInt("max_num_frames", self.early_stop)
+        self.ale.setFloat("repeat_action_probability", 0)   # sticky actions off
+        self.ale.setInt("frame_skip", 0)
+        self.ale.setBool("color_averaging", False)
+        self.ale.loadROM(rom)                               # after the options
+        actions = self.ale.getMinimalActionSet()
+        self.actions = dict(enumerate(actions))
+        self.lives = 0
+        self.just_died = False      # lost a life but the game is not over
+        self.exp_state1 = deque(maxlen=self.state_cha)
+        self._reset_experience()
+
+    def _reset_experience(self):
+        self.exp_state0 = None
+        self.exp_action = None
+        self.exp_reward = None
+        self.exp_terminal1 = None
+        if isinstance(getattr(self, "exp_state1", None), deque):
+            for _ in range(self.state_cha):
+                self.exp_state1.append(np.zeros((self.state_hei, self.state_wid), dtype=np.uint8))
+
+    def _capture_ale(self):
+        return resize_bilinear_u8(self.ale.getScreenGrayscale().squeeze(), self.state_hei, self.state_wid)
+
+    def _preprocess_state(self, state):
+        return np.stack(state, axis=0)
+
+    def _preprocess_action(self, action):
+        return np.asarray(action).reshape(self.action_shape)
+
+    @property
+    def norm_val(self):
+        return 255.0
+
+    @property
+    def state_shape(self):
+        return [self.state_cha, self.state_hei, self.state_wid]
+
+    @property
+    def action_shape(self):
+        return 1
+
+    @property
+    def action_space(self):
+        return len(self.actions)
+
+    def step(self, action):
+        self.exp_action = self._preprocess_action(action)
+        frames = np.zeros((2, self.state_hei, self.state_wid), dtype=np.uint8)
+        self.exp_reward = 0.0
+        self.exp_terminal1 = False
+        ale_action = self.actions.get(int(np.asarray(action).reshape(-1)[0]))
+        for t in range(4):          # repeat 4x, max-pool the last two frames
+            self.exp_reward += self.ale.act(ale_action)
+            if t >= 2:
+                frames[t - 2] = self._capture_ale()
+            self.exp_terminal1 = self.ale.game_over()
+            if self.exp_terminal1:
+                break
+        self.exp_state1.append(np.maximum(frames[0], frames[1]))
+        if self.training:           # loss of life is terminal while training
+            lives = self.ale.lives()
+            if 0 < lives < self.lives:
+                self.just_died = not self.exp_terminal1
+                self.exp_terminal1 = True
+            self.lives = lives
+        return self._get_experience()
+
+    def reset(self):
+        if self.just_died:
+            self.just_died = False
+            self.ale.act(0)         # no-op after a lost life
+        else:
+            self._reset_experience()
+            self.ale.reset_game()
+            for _ in range(self.rng.randint(30)):   # up to 30 no-ops
+                self.ale.act(0)
+                if self.ale.game_over():
+                    self.ale.reset_game()
+        self.exp_state1.append(self._capture_ale())
+        self.lives = self.ale.lives()
+        return self._get_experience()
+
+
+def make_atari_env(args, process_ind=0, num_envs_per_process=1):
+    """Factory entry for env_type "atari": real ALE when importable, otherwise
+    Atari-shaped synthetic frames (with a warning)."""
+    if _find_ale() is not None:
+        return AtariEnv(args, process_ind, num_envs_per_process)
+    from .synthetic_env import SyntheticAtariEnv
+    if process_ind == 0:
+        warnings.warn("ALE is not installed: env_type 'atari' is using SyntheticAtariEnv frames")
+    return SyntheticAtariEnv(args, process_ind, num_envs_per_process)

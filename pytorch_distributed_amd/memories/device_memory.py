@@ -1,0 +1,196 @@
+"""HBM-resident replay fed by many CPU actors without host round-trips on the
+learner path.
+
+The reference keeps replay in host shm behind one lock, casts sampled states to
+float32 on the CPU and ships 28.9 MB per step over PCIe from unpinned memory
+(core/memories/shared_memory.py:59-75, dqn_learner.py:63-64).  Here:
+
+  actors --feed()--> lock-free shm ring (parallel/ingest.py, C++)
+         learner: drain() pops a chunk into pinned memory, one async H2D copy,
+         one unpack kernel scatters it into the HBM ring (uint8 states stay uint8)
+         sample_indices(): uniform draw, or wave-per-sample descent of the HIP
+         radix-64 sum tree with importance weights (memory_type "device-per")
+         the conv1 kernel then reads frames *through the index vector*:
+         no gather copy, no float inflation, no H2D in the step.
+
+One object, two faces: pickled to actor processes it only exposes feed()/size;
+in a learner process `attach(device, rank, world)` allocates that rank's shard
+(memory_size / world transitions; 2M x 2 x 28 KB = 113 GB fits one MI355X).
+With replay_device="cpu" the same code runs on host tensors (tests, no-GPU).
+"""
+import numpy as np
+import torch
+from ..utils import mpctx as mp
+
+from ..ops import replay as replay_ops
+from ..ops.segtree import DeviceSumMinTree
+from ..parallel.ingest import ShmRing, TransitionCodec
+from .memory import Memory
+
+
+class DeviceMemory(Memory):
+    def __init__(self, args):
+        super().__init__(args)
+        self.replay_device = getattr(args, "replay_device", "cpu")
+        self.codec = TransitionCodec(self.state_shape, self.state_dtype, self.action_shape, self.reward_shape)
+        self.ring = ShmRing(int(getattr(args, "ingest_ring_slots", 4096)), self.codec.record_bytes)
+        self.ingest_chunk = int(getattr(args, "ingest_chunk", 256))
+        self.shared_size = mp.Value("l", 0)     # rank 0's resident transitions, visible to every process
+        self.total_fed = mp.Value("l", 0)
+        self.attached = False
+        self._gen = None
+
+    # ---- actor face ------------------------------------------------------------
+    def feed(self, experience, priority=0.0):
+        state0, action, reward, gamma1, state1, terminal1 = experience
+        c = self.codec
+        s0 = np.ascontiguousarray(state0, dtype=c.state_np).reshape(-1)
+        s1 = np.ascontiguousarray(state1, dtype=c.state_np).reshape(-1)
+        pad = c.state_stride - c.state_bytes
+        tail = c.tail(action, reward, gamma1, terminal1, priority)
+        if pad:
+            z = np.zeros(pad, dtype=np.uint8)
+            s0 = np.concatenate([s0.view(np.uint8), z])
+            s1 = np.concatenate([s1.view(np.uint8), z])
+        ok = self.ring.push_segments([s0, s1, tail])
+        if not ok:
+            raise RuntimeError("replay ingestion ring stayed full for 30 s (is a learner draining it?)")
+
+    @property
+    def size(self):
+        if self.attached:
+            return self.memory_size if self.full else self.pos
+        return self.shared_size.value
+
+    def __getstate__(self):
+        if self.attached:
+            raise RuntimeError("an attached DeviceMemory cannot be pickled; pass it to children before attach()")
+        return self.__dict__.copy()
+
+    # ---- learner face --------------------------------------------------------------
+    def attach(self, device, rank=0, world_size=1):
+        c = self.codec
+        self.device = torch.device(device if self.replay_device != "cpu" else "cpu")
+        self.rank, self.world_size = rank, world_size
+        self.memory_size = max(self.memory_size // world_size, 1)
+        m = self.memory_size
+        dev = self.device
+        self.state0s = torch.zeros((m,) + tuple(self.state_shape), dtype=self.state_dtype, device=dev)
+        self.state1s = torch.zeros((m,) + tuple(self.state_shape), dtype=self.state_dtype, device=dev)
+        self.tails = torch.zeros(m, c.tail_floats, dtype=torch.float32, device=dev)
+        a, k = c.action_shape, c.num_tasks
+        self.actions = self.tails[:, :a]
+        self.rewards = self.tails[:, a:a + k]
+        self.gamma1s = self.tails[:, a + k:a + 2 * k]
+        self.terminal1s = self.tails[:, a + 2 * k:a + 3 * k]
+        self.init_priorities = self.tails[:, a + 3 * k]
+        self.staging = torch.zeros(self.ingest_chunk, c.record_bytes, dtype=torch.uint8)
+        if dev.type == "cuda":
+            self.staging = self.staging.pin_memory()
+            self.staging_dev = torch.zeros_like(self.staging, device=dev)
+            self.copy_stream = torch.cuda.Stream(device=dev)
+        else:
+            self.staging_dev = self.staging
+        self.tree = DeviceSumMinTree(m, dev) if self.enable_per else None
+        self._gen = torch.Generator(device=dev)
+        self._gen.manual_seed(1234 + rank)
+        self.pos, self.full = 0, False
+        self.attached = True
+        return self
+
+    def _leaf_priority(self, raw):
+        return (raw.abs() + self.priority_eps) ** self.priority_exponent
+
+    def ingest_records(self, records_dev, n):
+        """Scatter n packed records (already on the replay device) into the ring."""
+        m = self.memory_size
+        positions = (torch.arange(n, device=self.device, dtype=torch.int64) + self.pos) % m
+        positions = positions.to(torch.int32)
+        c = self.codec
+        replay_ops.unpack_records(records_dev, n, positions, self.state0s, self.state1s, self.tails,
+                                  c.state_bytes, c.state_stride, c.tail_floats)
+        if self.tree is not None:
+            self.tree.update(positions, self._leaf_priority(self.init_priorities[positions.long()]))
+        self.pos += n
+        if self.pos >= m:
+            self.full = True
+            self.pos -= m
+        self.total_fed.value += n
+        if self.rank == 0:
+            self.shared_size.value = self.size
+
+    def drain(self, max_chunks=4):
+        """Move up to max_chunks*ingest_chunk transitions ring -> HBM.  Returns count."""
+        moved = 0
+        for _ in range(max_chunks):
+            n = self.ring.pop_many(self.staging, self.ingest_chunk)
+            if n == 0:
+                break
+            if self.device.type == "cuda":
+                # the staging buffer is reused next iteration: copy on the current
+                # stream (ordered before the unpack kernel), pinned -> async DMA
+                self.staging_dev[:n].copy_(self.staging[:n], non_blocking=True)
+                torch.cuda.current_stream(self.device).synchronize()
+            self.ingest_records(self.staging_dev, n)
+            moved += n
+            if n < self.ingest_chunk:
+                break
+        return moved
+
+    def feed_batch(self, state0s, actions, rewards, gamma1s, state1s, terminal1s, priorities=None):
+        """Direct device-side ingestion of n transitions already on the replay
+        device (used by the on-GPU actor pool and the benchmark fill)."""
+        n = state0s.shape[0]
+        m = self.memory_size
+        pos = ((torch.arange(n, device=self.device) + self.pos) % m)
+        self.state0s[pos] = state0s.to(self.state_dtype)
+        self.state1s[pos] = state1s.to(self.state_dtype)
+        self.actions[pos] = actions.reshape(n, -1).float()
+        self.rewards[pos] = rewards.reshape(n, -1).float()
+        self.gamma1s[pos] = gamma1s.reshape(n, -1).float()
+        self.terminal1s[pos] = terminal1s.reshape(n, -1).float()
+        if priorities is None:
+            priorities = torch.ones(n, device=self.device)
+        self.init_priorities[pos] = priorities.float()
+        if self.tree is not None:
+            self.tree.update(pos.to(torch.int32), self._leaf_priority(priorities.float()))
+        self.pos += n
+        if self.pos >= m:
+            self.full = True
+            self.pos %= m
+        self.total_fed.value += n
+        if self.rank == 0:
+            self.shared_size.value = self.size
+
+    # ---- sampling --------------------------------------------------------------------
+    def sample_indices(self, batch_size, out_idx=None, out_weight=None):
+        """(idx int32 (B,), weights fp32 (B,)) on the replay device, no host sync."""
+        if self.tree is not None:
+            u = torch.rand(batch_size, device=self.device, generator=self._gen)
+            return self.tree.sample(u, self.priority_weight, out_idx, out_weight)
+        idx = torch.randint(0, max(self.size, 1), (batch_size,), device=self.device,
+                            generator=self._gen, dtype=torch.int32)
+        w = torch.ones(batch_size, device=self.device)
+        if out_idx is not None:
+            out_idx.copy_(idx)
+            out_weight.copy_(w)
+            return out_idx, out_weight
+        return idx, w
+
+    def _gather(self, idx):
+        li = idx.long()
+        return (replay_ops.gather_states(self.state0s, idx), self.actions[li], self.rewards[li],
+                self.gamma1s[li], replay_ops.gather_states(self.state1s, idx), self.terminal1s[li])
+
+    def sample(self, batch_size):
+        idx, _ = self.sample_indices(batch_size)
+        return self._gather(idx)
+
+    def sample_with_priorities(self, batch_size):
+        idx, w = self.sample_indices(batch_size)
+        return self._gather(idx), idx, w.reshape(-1, 1)
+
+    def update_priorities(self, indices, td_abs):
+        if self.tree is None or indices is None:
+            return
+        self.tree.update(indices.to(torch.int32), self._leaf_priority(td_abs.detach().reshape(-1).float()))

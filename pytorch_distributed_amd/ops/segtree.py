@@ -1,0 +1,150 @@
+"""Device-resident sum/min segment tree for prioritized replay (kernels K7/K8).
+
+Finishes what the reference left as dead code (utils/segment_tree.py:13-69) and
+re-shapes it for CDNA4: instead of a binary tree walked one dependent load per
+level (21 levels for 2M leaves), the tree has RADIX 64 -- one child per lane of
+a 64-wide wavefront.  A sample is one wave: at each level the 64 lanes load the
+64 children of the current node in one coalesced 256 B read, run a wave-level
+inclusive scan (DPP/shuffles), ballot for the first lane whose prefix reaches the
+target mass and descend.  2M leaves are 4 levels (64^4 = 16.7M) instead of 21.
+Priority updates write the leaves, then repair one level per launch with a
+64-lane wave reduction per touched node (idempotent on duplicates, no atomics,
+deterministic).
+
+`DeviceSumMinTree` holds both trees in one fp32 buffer.  On CPU tensors the same
+API runs a torch/numpy fallback with identical layout and results (used by the
+no-GPU tests and as the oracle's second opinion next to utils.SumMinTree).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib, native_available
+
+RADIX = 64
+
+
+def level_sizes(num_leaves):
+    """Padded node counts per level, leaves first; the last level has <= 64 nodes."""
+    sizes = [max(RADIX, (num_leaves + RADIX - 1) // RADIX * RADIX)]
+    while sizes[-1] > RADIX:
+        n = (sizes[-1] + RADIX - 1) // RADIX
+        sizes.append(n if n <= RADIX else (n + RADIX - 1) // RADIX * RADIX)
+    return sizes
+
+
+class DeviceSumMinTree(object):
+    def __init__(self, num_leaves, device):
+        self.num_leaves = int(num_leaves)
+        self.device = torch.device(device)
+        self.sizes = level_sizes(self.num_leaves)
+        self.offsets = [0]
+        for s in self.sizes[:-1]:
+            self.offsets.append(self.offsets[-1] + s)
+        self.total_nodes = self.offsets[-1] + RADIX     # top level padded to 64
+        self.depth = len(self.sizes)
+        self.sum = torch.zeros(self.total_nodes, dtype=torch.float32, device=self.device)
+        self.min = torch.full((self.total_nodes,), float("inf"), dtype=torch.float32, device=self.device)
+        self.native = self.device.type == "cuda" and native_available()
+        if self.device.type == "cuda" and not self.native:
+            from . import native_error
+            raise RuntimeError("DeviceSumMinTree on a GPU needs the HIP library: " + native_error())
+        self._offs_t = torch.tensor(self.offsets + [0] * (8 - len(self.offsets)), dtype=torch.int32)
+        assert self.depth <= 8
+
+    # ---- level helpers (fallback) -----------------------------------------
+    def _repair_cpu(self, leaf_inds):
+        idx = torch.unique(leaf_inds.long())
+        for lvl in range(1, self.depth):
+            idx = torch.unique(idx // RADIX)
+            child0 = self.offsets[lvl - 1] + idx * RADIX
+            gather = child0[:, None] + torch.arange(RADIX)[None, :]
+            self.sum[self.offsets[lvl] + idx] = self.sum[gather].sum(1)
+            self.min[self.offsets[lvl] + idx] = self.min[gather].min(1)[0]
+
+    # ---- API -----------------------------------------------------------------
+    def update(self, leaf_inds, values):
+        """leaf_inds (n,) int, values (n,) fp32 already in priority space."""
+        n = int(leaf_inds.numel())
+        if n == 0:
+            return
+        leaf_inds = leaf_inds.to(self.device, torch.int32).contiguous()
+        values = values.to(self.device, torch.float32).contiguous().reshape(-1)
+        if not self.native:
+            self.sum[leaf_inds.long()] = values
+            self.min[leaf_inds.long()] = values
+            self._repair_cpu(leaf_inds)
+            return
+        L = lib()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        L.pda_segtree_set_leaves(_p(self.sum), _p(self.min), _p(leaf_inds), _p(values), n, _s(stream))
+        self.repair(leaf_inds, n)
+
+    def repair(self, leaf_inds, n=None):
+        """Recompute every ancestor of the given leaves (their values were already
+        written, e.g. by the fused TD kernel)."""
+        n = int(leaf_inds.numel()) if n is None else n
+        if not self.native:
+            self._repair_cpu(leaf_inds.cpu())
+            return
+        L = lib()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        for lvl in range(1, self.depth):
+            L.pda_segtree_repair_level(_p(self.sum), _p(self.min), _p(leaf_inds), n,
+                                       self.offsets[lvl - 1], self.offsets[lvl], lvl, _s(stream))
+
+    def total(self):
+        top = self.offsets[-1]
+        return self.sum[top:top + RADIX].sum()
+
+    def min_value(self):
+        top = self.offsets[-1]
+        return self.min[top:top + RADIX].min()
+
+    def get(self, leaf_inds):
+        return self.sum[leaf_inds.long()]
+
+    def sample(self, uniforms, beta, out_idx=None, out_weight=None):
+        """Stratified draw: sample i targets mass (i + uniforms[i]) / B * total.
+        Returns (idx int32 (B,), importance weight fp32 (B,) = (p_min/p_i)^beta)."""
+        B = int(uniforms.numel())
+        if out_idx is None:
+            out_idx = torch.empty(B, dtype=torch.int32, device=self.device)
+        if out_weight is None:
+            out_weight = torch.empty(B, dtype=torch.float32, device=self.device)
+        if self.native:
+            L = lib()
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            offs = (ctypes.c_int * 8)(*([int(o) for o in self.offsets] + [0] * (8 - self.depth)))
+            L.pda_segtree_sample(_p(self.sum), _p(self.min), offs, self.depth, self.num_leaves,
+                                 _p(uniforms), B, ctypes.c_float(beta), _p(out_idx), _p(out_weight), _s(stream))
+            return out_idx, out_weight
+        total = self.total().double()
+        v = ((torch.arange(B, dtype=torch.float64) + uniforms.double().cpu()) / B * total).float()
+        node = torch.zeros(B, dtype=torch.long)
+        for lvl in range(self.depth - 1, -1, -1):
+            base = self.offsets[lvl] + node * RADIX
+            kids = self.sum[base[:, None] + torch.arange(RADIX)[None, :]]
+            csum = torch.cumsum(kids, 1)
+            hit = (csum >= v[:, None]) & (kids > 0)
+            any_hit = hit.any(1)
+            first = torch.where(any_hit, hit.float().argmax(1),
+                                (kids > 0).float().cumsum(1).argmax(1))     # last positive child
+            excl = torch.gather(csum - kids, 1, first[:, None])[:, 0]
+            v = v - excl
+            node = node * RADIX + first
+        idx = node.clamp_(max=self.num_leaves - 1)
+        p = self.sum[idx]
+        w = (self.min_value() / p.clamp_min(1e-30)) ** beta
+        out_idx.copy_(idx.to(torch.int32))
+        out_weight.copy_(w)
+        return out_idx, out_weight
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _s(stream):
+    return ctypes.c_void_p(stream)

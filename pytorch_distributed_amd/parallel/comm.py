@@ -1,0 +1,183 @@
+"""Collectives for data-parallel learners and weight distribution.
+
+The reference has no collectives at all: extra learners are Hogwild writers on
+one shared CUDA model.  Here learners are synchronous
+data-parallel ranks, one process per MI355X, and everything they exchange is a
+single flat fp32 buffer:
+
+* `all_reduce_mean_(flat_grads)`   one RCCL all-reduce per step (6.75 MB for
+  the Nature CNN -- latency-bound on xGMI, so exactly one launch, no bucketing);
+  optionally issued on a side stream so it overlaps the tail of backward;
+* `broadcast_(flat_params, src)`   initial weight sync and learner -> inference
+  rank weight publish;
+* `all_agree(flag)`                MIN-reduce of a readiness flag so every rank
+  enters (and leaves) the collective loop on the same step.
+
+`TorchComm` wraps torch.distributed ("nccl" is RCCL on ROCm; "gloo" on CPU).
+`FakeComm` is an in-process stand-in (world of W logical ranks sharing tensors)
+so the DP arithmetic is unit-testable with no process group at all;
+`SingleComm` is the world_size == 1 degenerate path.
+"""
+import os
+
+import torch
+
+try:
+    import torch.distributed as dist
+except Exception:   # pragma: no cover
+    dist = None
+
+
+class SingleComm(object):
+    rank, world_size = 0, 1
+
+    def all_reduce_mean_(self, flat, async_op=False):
+        return None
+
+    def all_reduce_sum_(self, flat):
+        return flat
+
+    def broadcast_(self, flat, src=0):
+        return flat
+
+    def all_agree(self, flag):
+        return bool(flag)
+
+    def barrier(self):
+        pass
+
+    def wait(self, handle):
+        pass
+
+    def close(self):
+        pass
+
+
+class TorchComm(SingleComm):
+    """torch.distributed-backed communicator (RCCL on GPU, gloo on CPU)."""
+
+    def __init__(self, rank, world_size, device, init_method=None, backend=None, timeout_s=600):
+        import datetime
+        self.rank, self.world_size = rank, world_size
+        self.device = torch.device(device)
+        if backend is None:
+            backend = "nccl" if self.device.type == "cuda" else "gloo"
+        self.backend = backend
+        self.owns_group = False
+        if not dist.is_initialized():
+            kwargs = dict(backend=backend, rank=rank, world_size=world_size,
+                          timeout=datetime.timedelta(seconds=timeout_s))
+            if init_method is not None:
+                kwargs["init_method"] = init_method
+            if backend == "nccl":
+                torch.cuda.set_device(self.device)
+                try:
+                    kwargs["device_id"] = self.device
+                except Exception:
+                    pass
+            dist.init_process_group(**kwargs)
+            self.owns_group = True
+        self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    def all_reduce_mean_(self, flat, async_op=False):
+        """In-place mean over ranks.  With async_op the reduce runs on a side
+        stream after everything already queued on the current stream; call
+        wait(handle) before consuming `flat`."""
+        if self.comm_stream is not None and async_op:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat.mul_(1.0 / self.world_size)
+            return self.comm_stream
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / self.world_size)
+        return None
+
+    def wait(self, handle):
+        if handle is not None:
+            torch.cuda.current_stream(self.device).wait_stream(handle)
+
+    def all_reduce_sum_(self, flat):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
+
+    def broadcast_(self, flat, src=0):
+        dist.broadcast(flat, src=src)
+        return flat
+
+    def all_agree(self, flag):
+        self._flag.fill_(1 if flag else 0)
+        dist.all_reduce(self._flag, op=dist.ReduceOp.MIN)
+        return bool(self._flag.item())
+
+    def barrier(self):
+        dist.barrier()
+
+    def close(self):
+        if self.owns_group and dist.is_initialized():
+            dist.destroy_process_group()
+
+
+class FakeComm(SingleComm):
+    """W logical ranks inside one process.  Each rank registers its tensor for a
+    collective; the last arrival performs it for everybody.  Used by unit tests
+    to check DP == large-batch equivalence without a process group."""
+
+    class _World(object):
+        def __init__(self, world_size):
+            self.world_size = world_size
+            self.pending = {}
+
+    def __init__(self, world, rank):
+        self.world, self.rank, self.world_size = world, rank, world.world_size
+
+    @classmethod
+    def create(cls, world_size):
+        w = cls._World(world_size)
+        return [cls(w, r) for r in range(world_size)]
+
+    def _collect(self, key, tensor, fn):
+        slot = self.world.pending.setdefault(key, [])
+        slot.append(tensor)
+        if len(slot) == self.world_size:
+            fn(slot)
+            del self.world.pending[key]
+
+    def all_reduce_mean_(self, flat, async_op=False):
+        def fn(ts):
+            total = torch.stack([t.detach().clone() for t in ts]).sum(0) / len(ts)
+            for t in ts:
+                t.copy_(total)
+        self._collect("arm", flat, fn)
+
+    def all_reduce_sum_(self, flat):
+        def fn(ts):
+            total = torch.stack([t.detach().clone() for t in ts]).sum(0)
+            for t in ts:
+                t.copy_(total)
+        self._collect("ars", flat, fn)
+        return flat
+
+    def broadcast_(self, flat, src=0):
+        def fn(ts):
+            for t in ts:
+                t.copy_(ts[src])
+        self._collect("bc", flat, fn)     # ranks must call in rank order
+        return flat
+
+
+def make_comm(rank, world_size, device, port=None, backend=None):
+    if world_size <= 1:
+        return SingleComm()
+    port = port or int(os.environ.get("PDA_DIST_PORT", "29533"))
+    return TorchComm(rank, world_size, device, init_method="tcp://127.0.0.1:%d" % port, backend=backend)
+
+
+def comm_from_env(device):
+    """Build a communicator from torchrun's RANK/WORLD_SIZE/MASTER_* env."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world <= 1:
+        return SingleComm()
+    return TorchComm(rank, world, device)

@@ -1,0 +1,185 @@
+// Lock-free bounded MPMC ring over a caller-provided shared-memory region.
+//
+// Many CPU actor processes push fixed-size transition records; learner ranks
+// pop them in batches straight into a pinned staging buffer that is then DMA'd
+// to HBM-resident replay.  Replaces the reference's single mp.Lock around every
+// feed and sample (core/memories/shared_memory.py:69-75), which serialises all
+// actors behind the learner's gather.
+//
+// Algorithm: per-slot sequence numbers (bounded MPMC queue).  A producer claims
+// position `pos` by CAS on `head` when slot.seq == pos, writes the payload, then
+// publishes with slot.seq = pos + 1 (release).  A consumer claims `pos` by CAS on
+// `tail` when slot.seq == pos + 1, reads, then frees with slot.seq = pos + N.
+// No syscalls, no locks; a stalled producer only delays its own slot.
+//
+// The region is plain memory (a torch shared-memory tensor on the Python side),
+// so the same code works across spawn'ed processes.  C ABI for ctypes.
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <new>
+
+namespace {
+
+constexpr uint64_t kMagic = 0x50444152494e4731ull;  // "PDARING1"
+constexpr size_t kLine = 64;
+
+struct alignas(kLine) Header {
+    uint64_t magic;
+    uint32_t num_slots;      // power of two
+    uint32_t payload_bytes;  // bytes copied per record
+    uint32_t slot_stride;    // bytes between slots (header + padded payload)
+    uint32_t reserved;
+    alignas(kLine) std::atomic<uint64_t> head;
+    alignas(kLine) std::atomic<uint64_t> tail;
+    alignas(kLine) std::atomic<uint64_t> pushed;
+    alignas(kLine) std::atomic<uint64_t> popped;
+    alignas(kLine) std::atomic<uint64_t> full_events;
+};
+
+struct alignas(kLine) Slot {
+    std::atomic<uint64_t> seq;
+};
+
+static_assert(std::atomic<uint64_t>::is_always_lock_free, "need lock-free 64-bit atomics");
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline Header* hdr(void* base) { return reinterpret_cast<Header*>(base); }
+inline char* slots_base(void* base) { return reinterpret_cast<char*>(base) + sizeof(Header); }
+inline Slot* slot_at(void* base, uint64_t pos) {
+    Header* h = hdr(base);
+    return reinterpret_cast<Slot*>(slots_base(base) + (pos & (h->num_slots - 1)) * (size_t)h->slot_stride);
+}
+inline char* payload_of(Slot* s) { return reinterpret_cast<char*>(s) + sizeof(Slot); }
+
+}  // namespace
+
+extern "C" {
+
+// Bytes the region must have for `num_slots` records of `payload_bytes`.
+uint64_t pda_ring_bytes(uint32_t num_slots, uint32_t payload_bytes) {
+    return sizeof(Header) + (uint64_t)num_slots * (sizeof(Slot) + round_up(payload_bytes, kLine));
+}
+
+// Initialise (once, before any producer/consumer starts).  Returns 0 on success.
+int pda_ring_init(void* base, uint64_t region_bytes, uint32_t num_slots, uint32_t payload_bytes) {
+    if (num_slots == 0 || (num_slots & (num_slots - 1)) != 0) return -1;
+    if (reinterpret_cast<uintptr_t>(base) % kLine != 0) return -2;
+    if (region_bytes < pda_ring_bytes(num_slots, payload_bytes)) return -3;
+    Header* h = new (base) Header();
+    h->num_slots = num_slots;
+    h->payload_bytes = payload_bytes;
+    h->slot_stride = (uint32_t)(sizeof(Slot) + round_up(payload_bytes, kLine));
+    h->head.store(0, std::memory_order_relaxed);
+    h->tail.store(0, std::memory_order_relaxed);
+    h->pushed.store(0, std::memory_order_relaxed);
+    h->popped.store(0, std::memory_order_relaxed);
+    h->full_events.store(0, std::memory_order_relaxed);
+    for (uint32_t i = 0; i < num_slots; ++i) {
+        Slot* s = new (slots_base(base) + (size_t)i * h->slot_stride) Slot();
+        s->seq.store(i, std::memory_order_relaxed);
+    }
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    h->magic = kMagic;
+    return 0;
+}
+
+int pda_ring_valid(void* base) { return hdr(base)->magic == kMagic ? 1 : 0; }
+
+// Push one record assembled from up to 4 source segments (scatter-gather, so the
+// caller never builds an intermediate copy).  Returns 1 on success, 0 if full.
+int pda_ring_push(void* base, const void* seg0, uint32_t n0, const void* seg1, uint32_t n1,
+                  const void* seg2, uint32_t n2, const void* seg3, uint32_t n3) {
+    Header* h = hdr(base);
+    if ((uint64_t)n0 + n1 + n2 + n3 > h->payload_bytes) return -1;
+    uint64_t pos = h->head.load(std::memory_order_relaxed);
+    Slot* s;
+    for (;;) {
+        s = slot_at(base, pos);
+        uint64_t seq = s->seq.load(std::memory_order_acquire);
+        int64_t dif = (int64_t)(seq - pos);
+        if (dif == 0) {
+            if (h->head.compare_exchange_weak(pos, pos + 1, std::memory_order_relaxed)) break;
+        } else if (dif < 0) {
+            h->full_events.fetch_add(1, std::memory_order_relaxed);
+            return 0;
+        } else {
+            pos = h->head.load(std::memory_order_relaxed);
+        }
+    }
+    char* dst = payload_of(s);
+    if (n0) { std::memcpy(dst, seg0, n0); dst += n0; }
+    if (n1) { std::memcpy(dst, seg1, n1); dst += n1; }
+    if (n2) { std::memcpy(dst, seg2, n2); dst += n2; }
+    if (n3) { std::memcpy(dst, seg3, n3); }
+    s->seq.store(pos + 1, std::memory_order_release);
+    h->pushed.fetch_add(1, std::memory_order_relaxed);
+    return 1;
+}
+
+// Pop up to max_records into dst (records packed dst_stride bytes apart).
+// Returns the number popped (0 when empty).
+int pda_ring_pop_many(void* base, void* dst, uint32_t dst_stride, uint32_t max_records) {
+    Header* h = hdr(base);
+    uint32_t got = 0;
+    char* out = reinterpret_cast<char*>(dst);
+    while (got < max_records) {
+        uint64_t pos = h->tail.load(std::memory_order_relaxed);
+        Slot* s;
+        bool empty = false;
+        for (;;) {
+            s = slot_at(base, pos);
+            uint64_t seq = s->seq.load(std::memory_order_acquire);
+            int64_t dif = (int64_t)(seq - (pos + 1));
+            if (dif == 0) {
+                if (h->tail.compare_exchange_weak(pos, pos + 1, std::memory_order_relaxed)) break;
+            } else if (dif < 0) {
+                empty = true;
+                break;
+            } else {
+                pos = h->tail.load(std::memory_order_relaxed);
+            }
+        }
+        if (empty) break;
+        std::memcpy(out + (size_t)got * dst_stride, payload_of(s), h->payload_bytes);
+        s->seq.store(pos + h->num_slots, std::memory_order_release);
+        ++got;
+    }
+    if (got) h->popped.fetch_add(got, std::memory_order_relaxed);
+    return (int)got;
+}
+
+uint64_t pda_ring_pushed(void* base) { return hdr(base)->pushed.load(std::memory_order_relaxed); }
+uint64_t pda_ring_popped(void* base) { return hdr(base)->popped.load(std::memory_order_relaxed); }
+uint64_t pda_ring_full_events(void* base) { return hdr(base)->full_events.load(std::memory_order_relaxed); }
+uint64_t pda_ring_backlog(void* base) {
+    Header* h = hdr(base);
+    uint64_t hd = h->head.load(std::memory_order_relaxed), tl = h->tail.load(std::memory_order_relaxed);
+    return hd >= tl ? hd - tl : 0;
+}
+
+// ---- shared 64-bit counters / seqlocked mailboxes (actor <-> inference server) ----
+uint64_t pda_atomic_load(void* p) {
+    return reinterpret_cast<std::atomic<uint64_t>*>(p)->load(std::memory_order_acquire);
+}
+void pda_atomic_store(void* p, uint64_t v) {
+    reinterpret_cast<std::atomic<uint64_t>*>(p)->store(v, std::memory_order_release);
+}
+uint64_t pda_atomic_add(void* p, uint64_t v) {
+    return reinterpret_cast<std::atomic<uint64_t>*>(p)->fetch_add(v, std::memory_order_acq_rel);
+}
+// Spin (with pause) until *p >= target or `spins` iterations elapse.  Returns the
+// last value seen; lets a Python caller wait without a 50 us sleep granularity.
+uint64_t pda_atomic_wait_ge(void* p, uint64_t target, uint64_t spins) {
+    auto* a = reinterpret_cast<std::atomic<uint64_t>*>(p);
+    uint64_t v = a->load(std::memory_order_acquire);
+    for (uint64_t i = 0; i < spins && v < target; ++i) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+        v = a->load(std::memory_order_acquire);
+    }
+    return v;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+"""Loader for the host-side C++ runtime (`parallel/libpda_host.so`): the
+lock-free shared-memory ring and the atomics behind the inference mailbox.
+Pure host code (g++), so it builds and loads on a CPU-only box; built on first
+use if the in-tree .so is missing.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, "csrc", "shm_ring.cpp")
+LIB_PATH = os.path.join(_HERE, "libpda_host.so")
+_LIB = None
+
+
+def build(force=False, sanitize=None):
+    out = LIB_PATH if sanitize is None else LIB_PATH.replace(".so", "_%s.so" % sanitize)
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(SRC):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", out + ".tmp%d" % os.getpid(), SRC]
+    if sanitize:
+        cmd[1:1] = ["-fsanitize=%s" % sanitize, "-g"]
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp%d" % os.getpid(), out)
+    return out
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        u64, u32, vp, i32 = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int
+        L.pda_ring_bytes.restype = u64
+        L.pda_ring_bytes.argtypes = [u32, u32]
+        L.pda_ring_init.restype = i32
+        L.pda_ring_init.argtypes = [vp, u64, u32, u32]
+        L.pda_ring_valid.restype = i32
+        L.pda_ring_valid.argtypes = [vp]
+        L.pda_ring_push.restype = i32
+        L.pda_ring_push.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, u32]
+        L.pda_ring_pop_many.restype = i32
+        L.pda_ring_pop_many.argtypes = [vp, vp, u32, u32]
+        for name in ("pda_ring_pushed", "pda_ring_popped", "pda_ring_full_events", "pda_ring_backlog"):
+            getattr(L, name).restype = u64
+            getattr(L, name).argtypes = [vp]
+        L.pda_atomic_load.restype = u64
+        L.pda_atomic_load.argtypes = [vp]
+        L.pda_atomic_store.restype = None
+        L.pda_atomic_store.argtypes = [vp, u64]
+        L.pda_atomic_add.restype = u64
+        L.pda_atomic_add.argtypes = [vp, u64]
+        L.pda_atomic_wait_ge.restype = u64
+        L.pda_atomic_wait_ge.argtypes = [vp, u64, u64]
+        _LIB = L
+    return _LIB

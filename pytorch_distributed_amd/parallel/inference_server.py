@@ -1,0 +1,193 @@
+"""Batched actor inference: one GPU forward serves every env worker (kernel K10).
+
+The reference gives each actor process a private CUDA model and runs batch-1
+forwards with two `.item()` syncs per env step (dqn_actor.py:23-30,84;
+dqn_cnn_model.py:58-78).  Here actors are pure-CPU env loops that post their
+observation into a shared-memory mailbox slot; the server process gathers every
+pending slot, runs ONE batched forward on the MI355X (HIP engine: uint8 frames
+in, MFMA convs, epsilon-greedy/argmax/max-Q epilogue with a per-actor epsilon
+vector), and posts actions + q-values back.
+
+Mailbox protocol per slot i (all in one shared tensor block, 64-bit sequence
+words accessed with acquire/release atomics from parallel/csrc/shm_ring.cpp):
+  actor : write obs[i]; req[i] = k (release); wait resp[i] >= k; read out[i]
+  server: see req[i] > resp[i]; read obs[i]; ...forward...; write out[i];
+          resp[i] = req_seen (release)
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import hostlib
+from ..utils.param_store import sync_params
+
+
+class InferenceMailbox(object):
+    def __init__(self, num_slots, state_shape, state_dtype, action_shape, discrete=True):
+        self.num_slots = int(num_slots)
+        self.discrete = discrete
+        self.obs = torch.zeros((self.num_slots,) + tuple(state_shape), dtype=state_dtype).share_memory_()
+        self.seq = torch.zeros(self.num_slots, 16, dtype=torch.int64).share_memory_()  # [:,0]=req [:,8]=resp (separate lines)
+        self.out = torch.zeros(self.num_slots, int(action_shape) + 2, dtype=torch.float32).share_memory_()
+        self.eps = torch.zeros(self.num_slots, dtype=torch.float32).share_memory_()
+        self.closed = torch.zeros(1, dtype=torch.int64).share_memory_()     # set by the server on exit
+        self.action_shape = int(action_shape)
+        self._np = None
+        self._count = {}
+
+    def _views(self):
+        if self._np is None:
+            self._np = (self.obs.numpy(), self.out.numpy(), self.seq.data_ptr())
+        return self._np
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_np"] = None
+        d["_count"] = {}
+        return d
+
+    def set_epsilon(self, slot, eps):
+        self.eps[slot] = float(eps)
+
+    def _req_ptr(self, slot):
+        return self._views()[2] + slot * 128
+
+    def _resp_ptr(self, slot):
+        return self._views()[2] + slot * 128 + 64
+
+    # ---- actor side --------------------------------------------------------
+    def request(self, slot, state, timeout_s=120.0):
+        L = hostlib.lib()
+        obs, out, _ = self._views()
+        obs[slot] = state
+        k = self._count.get(slot)
+        if k is None:
+            k = int(L.pda_atomic_load(self._req_ptr(slot)))
+        k += 1
+        self._count[slot] = k
+        L.pda_atomic_store(self._req_ptr(slot), k)
+        deadline = time.time() + timeout_s
+        delay = 2e-5
+        while True:
+            if L.pda_atomic_wait_ge(self._resp_ptr(slot), k, 2000) >= k:
+                break
+            if int(self.closed[0]) != 0:      # job is shutting down: hand back a no-op action
+                a = self.action_shape
+                return (np.zeros((1, 1), dtype=np.int64) if self.discrete else np.zeros((1, a))), 0.0, 0.0
+            if time.time() > deadline:
+                raise TimeoutError("inference server did not answer slot %d" % slot)
+            time.sleep(delay)
+            delay = min(delay * 1.5, 1e-3)
+        a = self.action_shape
+        row = out[slot]
+        if self.discrete:
+            action = np.array([[int(row[0])]])
+        else:
+            action = row[:a].astype(np.float64).reshape(1, a)
+        return action, float(row[a]), float(row[a + 1])
+
+    # ---- server side -------------------------------------------------------------
+    def pending(self):
+        seq = self.seq.numpy()
+        req, resp = seq[:, 0].copy(), seq[:, 8]
+        ids = np.nonzero(req > resp)[0]
+        return ids, req[ids]
+
+    def respond(self, ids, req_seen, actions, qvalues, max_qvalues):
+        L = hostlib.lib()
+        _, out, _ = self._views()
+        a = self.action_shape
+        out[ids, :a] = np.asarray(actions, dtype=np.float32).reshape(len(ids), a)
+        out[ids, a] = qvalues
+        out[ids, a + 1] = max_qvalues
+        for i, k in zip(ids, req_seen):
+            L.pda_atomic_store(self._resp_ptr(int(i)), int(k))
+
+
+class BatchedPolicy(object):
+    """Device-side action selection for a batch of observations.  Uses the HIP
+    engine when available, the torch module otherwise."""
+
+    def __init__(self, args, model, device):
+        self.args, self.model, self.device = args, model, device
+        self.kind = args.agent_type
+        self.engine = None
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(args.seed + 4242)
+        if device.type == "cuda" and getattr(args, "compute", "auto") != "torch":
+            from .. import ops
+            if ops.native_available() and args.model_type == "dqn-cnn":
+                from ..ops.dqn_engine import DqnCnnInference
+                self.engine = DqnCnnInference(model, max_batch=max(args.num_actors, 1))
+
+    def refresh(self):
+        if self.engine is not None:
+            self.engine.refresh_weights()
+
+    @torch.no_grad()
+    def act(self, obs, eps):
+        """obs (n, ...) on device; eps (n,) on device.  Returns host arrays
+        (actions (n, A), q (n,), maxq (n,))."""
+        n = obs.shape[0]
+        if self.kind == "dqn":
+            if self.engine is not None:
+                a, q, mq = self.engine.act(obs, eps)
+            else:
+                qv = self.model(obs)
+                mq, greedy = qv.max(dim=1)
+                explore = torch.rand(n, device=self.device, generator=self.gen) < eps
+                rand_a = torch.randint(0, qv.shape[1], (n,), device=self.device, generator=self.gen)
+                a = torch.where(explore, rand_a, greedy)
+                q = qv.gather(1, a[:, None])[:, 0]
+            return a.float().cpu().numpy().reshape(n, 1), q.cpu().numpy(), mq.cpu().numpy()
+        act = self.model.forward_actor(obs)
+        z = np.zeros(n, dtype=np.float32)
+        return act.float().cpu().numpy(), z, z
+
+
+def inference_server(process_ind, args, global_logs, model_prototype, global_model):
+    print("---------------------------->", process_ind, "inference server")
+    mailbox = global_model.mailbox
+    device = torch.device(args.device if args.device != "cuda" else "cuda:%d" % args.gpu_ind)
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+    model = model_prototype(args.model_params, args.norm_val, args.state_shape,
+                            args.action_space, args.action_shape).to(device)
+    version = sync_params(model, global_model)
+    model.eval()
+    torch.set_grad_enabled(False)
+    policy = BatchedPolicy(args, model, device)
+    policy.refresh()
+    try:
+        _serve(args, global_logs, global_model, mailbox, model, policy, device, version)
+    finally:
+        mailbox.closed[0] = 1
+
+
+def _serve(args, global_logs, global_model, mailbox, model, policy, device, version):
+    eps_dev = None
+    served, last_sync = 0, 0
+    idle = 0
+    while global_logs.running(args.agent_params.steps):
+        ids, req_seen = mailbox.pending()
+        if len(ids) == 0:
+            idle += 1
+            time.sleep(2e-5 if idle < 200 else 5e-4)
+            continue
+        idle = 0
+        obs = mailbox.obs[torch.as_tensor(ids)]
+        if device.type == "cuda":
+            obs = obs.pin_memory().to(device, non_blocking=True)
+        if eps_dev is None or served - last_sync >= args.agent_params.actor_sync_freq:
+            eps_dev = mailbox.eps.to(device)
+        eps = eps_dev[torch.as_tensor(ids, device=device)]
+        actions, q, mq = policy.act(obs, eps)
+        mailbox.respond(ids, req_seen, actions, q, mq)
+        served += len(ids)
+        if served - last_sync >= args.agent_params.actor_sync_freq:
+            v = global_model.param_version.value
+            if v != version and v % 2 == 0:
+                version = sync_params(model, global_model)
+                policy.refresh()
+            last_sync = served

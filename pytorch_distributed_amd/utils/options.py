@@ -1,0 +1,280 @@
+"""Configuration: CONFIGS table + Params/EnvParams/MemoryParams/ModelParams/
+AgentParams/Options, same names and fields as the reference (utils/options.py:
+10-175) so "edit options.py, run main.py" still works -- but every object is an
+ordinary picklable *instance* (the reference builds the nested params as class
+attributes at import, utils/options.py:171-175), and any field can be overridden
+without editing the file:
+
+    Options(config=3, overrides={"num_actors": 8, "agent_params.nstep": 5})
+    PDA_OVERRIDES="num_actors=2,agent_params.steps=200" python main.py
+    python main.py config=4 agent_params.batch_size=4096
+
+Extra fields (absent in the reference) configure the MI355X-native paths:
+device selection, HBM replay, PER alpha/beta, batched actor inference,
+data-parallel learner ranks.
+"""
+import ast
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .random_process import OrnsteinUhlenbeckProcess
+
+CONFIGS = [
+    # agent_type, env_type,    game,        memory_type,  model_type
+    ["dqn",  "atari",     "pong",      "shared",     "dqn-cnn"],   # 0 reference row (ALE; synthetic frames if ALE is absent)
+    ["dqn",  "synthetic", "pong",      "shared",     "dqn-cnn"],   # 1 plumbing: 2 actors, nstep=1, CPU learner
+    ["dqn",  "synthetic", "pong",      "device",     "dqn-cnn"],   # 2 8 actors, nstep=5, one MI355X, batched actor inference
+    ["ddpg", "pendulum",  "pendulum",  "shared",     "ddpg-mlp"],  # 3 Distributed DDPG, 8 actors, n-step critic targets
+    ["dqn",  "synthetic", "pong",      "device-per", "dqn-cnn"],   # 4 Ape-X: 256 actors, 2M HBM replay, DP learners
+    ["dqn",  "synthetic", "pong",      "device-per", "dqn-cnn"],   # 5 large-batch (4096) prioritized DQN
+    ["dqn",  "chain",     "chain",     "shared",     "dqn-mlp"],   # 6 tiny learnable task for sanity tests
+    ["ddpg", "pendulum",  "pendulum",  "device",     "ddpg-mlp"],  # 7 DDPG with HBM replay + native kernels
+]
+
+# per-config presets applied after the defaults (dotted keys reach nested params)
+PRESETS = {
+    1: {"num_actors": 2, "agent_params.nstep": 1, "device": "cpu"},
+    2: {"num_actors": 8, "agent_params.nstep": 5, "actor_inference": "batched"},
+    3: {"num_actors": 8, "agent_params.nstep": 5},
+    4: {"num_actors": 256, "actor_inference": "batched", "memory_params.memory_size": 2 * 1024 * 1024,
+        "memory_params.enable_per": True, "agent_params.nstep": 5},
+    5: {"num_actors": 256, "actor_inference": "batched", "memory_params.memory_size": 1024 * 1024,
+        "memory_params.enable_per": True, "agent_params.batch_size": 4096},
+    6: {"num_actors": 2, "agent_params.nstep": 3, "agent_params.learn_start": 200,
+        "agent_params.batch_size": 32, "agent_params.target_model_update": 50,
+        "agent_params.lr": 1e-3, "memory_params.memory_size": 5000},
+    7: {"num_actors": 8, "agent_params.nstep": 5},
+}
+
+
+def _default_device():
+    return "cuda" if torch.cuda.is_available() else "cpu"
+
+
+def _parse_value(text):
+    if not isinstance(text, str):
+        return text
+    low = text.strip().lower()
+    if low in ("none", "null"):
+        return None
+    if low in ("inf", "+inf"):
+        return float("inf")
+    try:
+        return ast.literal_eval(text)
+    except (ValueError, SyntaxError):
+        return text
+
+
+def parse_overrides(items):
+    """["a=1", "b.c=x"] or "a=1,b.c=x" -> {"a": 1, "b.c": "x"}"""
+    if items is None:
+        return {}
+    if isinstance(items, dict):
+        return dict(items)
+    if isinstance(items, str):
+        items = [s for s in items.split(",") if s.strip()]
+    out = {}
+    for item in items:
+        if "=" not in item:
+            raise ValueError("override %r is not KEY=VALUE" % (item,))
+        k, v = item.split("=", 1)
+        out[k.strip()] = _parse_value(v.strip())
+    return out
+
+
+class Params(object):
+    def __init__(self, config=None, overrides=None):
+        overrides = overrides or {}
+        # training signature
+        self.machine = overrides.get("machine", "mi355x")      # "machine_id"
+        self.timestamp = overrides.get("timestamp", "26111000")  # "yymmdd##"
+        # training configuration
+        self.mode = overrides.get("mode", 1)                   # 1(train) | 2(test model_file)
+        self.config = overrides.get("config", 0 if config is None else config)
+        self.gpu_ind = overrides.get("gpu_ind", 0)             # first learner uses cuda:gpu_ind
+
+        (self.agent_type, self.env_type, self.game,
+         self.memory_type, self.model_type) = CONFIGS[self.config]
+
+        self.seed = 100
+        self.render = False
+        self.visualize = True
+
+        self.num_envs_per_actor = 1
+        self.num_actors = 8
+        self.num_learners = 1
+
+        # --- MI355X-native extensions -------------------------------------
+        self.device = _default_device()     # learner / inference device: "cuda" | "cpu"
+        self.actor_inference = "local"      # "local": per-actor model copy | "batched": GPU inference server
+        self.compute = "auto"               # "auto" | "native" (HIP kernels, bf16 MFMA) | "torch" (fp32 eager)
+        self.param_sync_freq = 25           # learner publishes weights every this many learner steps
+        self.supervise = True               # restart dead actors, stop everything if a learner dies
+        self.inject_fault = None            # e.g. "actor:1@50" kills actor 1 at its 50th step (tests)
+        self.ingest = "ring"                # "ring": lock-free shm ring into device replay | "direct"
+
+        # prefix for saving models&logs
+        self.root_dir = overrides.get("root_dir", os.getcwd())
+        self._refresh_paths()
+
+    def _refresh_paths(self):
+        self.refs = self.machine + "_" + self.timestamp
+        # NOTE: evaluator saves the current model to model_name
+        self.model_name = self.root_dir + "/models/" + self.refs + ".pth"
+        # NOTE: pretrained model_file is loaded for finetuning when not None
+        if not hasattr(self, "model_file"):
+            self.model_file = None
+        if self.mode == 2:
+            self.model_file = self.model_name   # mode=2 tests the current training's checkpoint
+            self.visualize = False
+        self.log_dir = self.root_dir + "/logs/" + self.refs + "/"
+
+
+class EnvParams(Params):
+    def __init__(self, config=None, overrides=None):
+        super().__init__(config, overrides)
+        if "mlp" in self.model_type:    # low-dim inputs, no preprocessing
+            self.state_cha = 1          # equals hist_len
+            self.state_hei = 1
+            self.state_wid = None       # depends on the env
+        elif "cnn" in self.model_type:  # raw image inputs
+            self.state_cha = 4
+            self.state_hei = 84
+            self.state_wid = 84
+        self.early_stop = None
+        if self.env_type in ("atari", "synthetic"):
+            self.early_stop = 12500
+        elif self.env_type == "pendulum":
+            self.early_stop = 200
+        elif self.env_type in ("chain", "counting"):
+            self.early_stop = 50
+        # synthetic env knobs
+        self.synthetic_episode_len = 1000   # mean steps per synthetic episode
+        self.synthetic_num_actions = 6      # Pong's minimal action set
+
+
+class MemoryParams(Params):
+    def __init__(self, config=None, overrides=None):
+        super().__init__(config, overrides)
+        self.memory_size = 50000
+        # dtype for states (the reference passes tensor *types* because dtypes
+        # did not pickle through mp at the time; both are kept here)
+        if "mlp" in self.model_type:
+            self.tensortype = torch.FloatTensor
+            self.state_dtype = "float32"
+        else:                           # images stay uint8 end to end
+            self.tensortype = torch.ByteTensor
+            self.state_dtype = "uint8"
+        # prioritized experience replay (finished here; a TODO in the reference)
+        self.enable_per = "per" in self.memory_type
+        self.priority_exponent = 0.5    # alpha (rainbow 0.5, ape-x 0.6)
+        self.priority_weight = 0.4      # beta
+        self.priority_eps = 1e-6
+        # device replay / ingestion
+        self.replay_device = _default_device() if "device" in self.memory_type else "cpu"
+        self.ingest_ring_slots = 4096   # transitions buffered in the shm ring
+        self.ingest_chunk = 256         # max transitions moved to HBM per drain
+
+
+class ModelParams(Params):
+    def __init__(self, config=None, overrides=None):
+        super().__init__(config, overrides)
+        self.init = "default"           # "default" (what the reference actually runs) | "orthogonal"
+
+
+class AgentParams(Params):
+    def __init__(self, config=None, overrides=None):
+        super().__init__(config, overrides)
+        # criteria and optimizer
+        self.value_criteria = nn.MSELoss()
+        self.optim = torch.optim.Adam
+        self.num_tasks = 1
+        self.steps = 500000             # max #learner iterations
+        self.gamma = 0.99
+        self.lr = 1e-4
+        self.lr_decay = False
+        self.weight_decay = 0.0
+        self.logger_freq = 15           # secs
+        self.tester_nepisodes = 50
+        self.evaluator_nepisodes = 2
+        self.nstep = 5
+        self.poll_interval = 5.0        # logger/evaluator wake-up period (secs; the reference hard-codes 5)
+        if self.agent_type == "dqn":
+            self.clip_grad = np.inf
+            self.actor_sync_freq = 100
+            self.actor_freq = 250
+            self.learner_freq = 100
+            self.evaluator_freq = 30
+            self.learn_start = 5000
+            self.batch_size = 128
+            self.target_model_update = 250
+            self.enable_double = False
+            self.eps = 0.4
+            self.eps_alpha = 7
+        elif self.agent_type == "ddpg":
+            self.clip_grad = 40.0
+            self.actor_sync_freq = 400
+            self.actor_freq = 2500
+            self.learner_freq = 1000
+            self.evaluator_freq = 60
+            self.learn_start = 250
+            self.batch_size = 64
+            self.target_model_update = 1e-3
+            self.random_process = OrnsteinUhlenbeckProcess
+            # the reference lets the actor loss deposit gradients into the critic
+            # (ddpg_learner.py:66-86); False freezes the critic during the actor loss
+            self.compat_ddpg_grad_leak = True
+
+
+_NESTED = ("env_params", "memory_params", "model_params", "agent_params")
+
+
+class Options(Params):
+    def __init__(self, config=None, overrides=None, argv=None):
+        ov = parse_overrides(os.environ.get("PDA_OVERRIDES"))
+        ov.update(parse_overrides(argv))
+        ov.update(parse_overrides(overrides))
+        if config is None and "config" in ov:
+            config = ov["config"]
+        top = {k: v for k, v in ov.items() if "." not in k}
+        super().__init__(config, top)
+        self.env_params = EnvParams(self.config, top)
+        self.memory_params = MemoryParams(self.config, top)
+        self.model_params = ModelParams(self.config, top)
+        self.agent_params = AgentParams(self.config, top)
+        merged = dict(PRESETS.get(self.config, {}))
+        merged.update(ov)
+        self.apply(merged)
+
+    def apply(self, overrides):
+        """Set fields; un-dotted keys also propagate into every nested params
+        object that carries the same field (they all inherit Params)."""
+        for key, val in overrides.items():
+            if key == "config":
+                continue
+            if "." in key:
+                head, field = key.split(".", 1)
+                if head not in _NESTED:
+                    raise KeyError("unknown params group %r" % head)
+                setattr(getattr(self, head), field, val)
+            else:
+                setattr(self, key, val)
+                for name in _NESTED:
+                    sub = getattr(self, name)
+                    if hasattr(sub, key):
+                        setattr(sub, key, val)
+        for obj in (self,) + tuple(getattr(self, n) for n in _NESTED):
+            obj._refresh_paths()
+        if "model_file" in overrides:
+            self.model_file = overrides["model_file"]
+        mp = self.memory_params
+        if "memory_params.enable_per" not in overrides:
+            mp.enable_per = "per" in self.memory_type
+        if mp.replay_device == "cuda" and not torch.cuda.is_available():
+            mp.replay_device = "cpu"
+        if self.device == "cuda" and not torch.cuda.is_available():
+            self.device = "cpu"
+        return self

@@ -1,0 +1,86 @@
+"""End-to-end plumbing with real spawned processes and no GPU (BASELINE.json
+config 1: Distributed DQN, 2 actors, nstep=1, CPU learner) plus DDPG, mode=2
+testing, batched inference, device-replay ingestion and actor restart."""
+import os
+
+import pytest
+import torch
+
+from pytorch_distributed_amd.launcher import run
+from pytorch_distributed_amd.utils.board import read_scalars
+from pytorch_distributed_amd.utils.checkpoint import load_state_dict
+from pytorch_distributed_amd.utils.options import Options
+
+FAST = {"device": "cpu", "agent_params.poll_interval": 0.2, "agent_params.logger_freq": 0.3,
+        "agent_params.evaluator_freq": 0.5, "agent_params.evaluator_nepisodes": 1,
+        "agent_params.actor_freq": 20, "agent_params.learner_freq": 5, "agent_params.actor_sync_freq": 20,
+        "param_sync_freq": 5, "env_params.early_stop": 40, "env_params.synthetic_episode_len": 20}
+
+
+def opts(config, root, **ov):
+    o = dict(FAST)
+    o.update({"root_dir": root, "timestamp": "t%d" % config})
+    o.update(ov)
+    return Options(config=config, overrides=o)
+
+
+def check_common(opt, sup, min_steps):
+    assert all(c == 0 for c in sup.exitcodes), sup.exitcodes
+    assert os.path.exists(opt.model_name)
+    tags = {s["tag"] for s in read_scalars(opt.log_dir)}
+    assert {"learner/critic_loss", "throughput/learner_updates_per_sec",
+            "throughput/actor_frames_per_sec", "evaluator/avg_reward"} <= tags
+    steps = [s["step"] for s in read_scalars(opt.log_dir)]
+    assert max(steps) >= min_steps
+
+
+def test_config1_dqn_cpu_plumbing_then_mode2(tmp_root):
+    opt = opts(1, tmp_root, **{"agent_params.steps": 30, "agent_params.learn_start": 40,
+                               "agent_params.batch_size": 16, "memory_params.memory_size": 500})
+    assert opt.num_actors == 2 and opt.agent_params.nstep == 1
+    sup = run(opt)
+    check_common(opt, sup, 30)
+    sd = load_state_dict(opt.model_name)
+    assert sd["critic.1.0.weight"].shape == (512, 3136)
+    tags = {s["tag"] for s in read_scalars(opt.log_dir)}
+    assert "actor/avg_reward" in tags and "actor/total_nframes" in tags
+    # mode=2: only flip the mode, the tester finds the checkpoint by signature
+    opt2 = opts(1, tmp_root, mode=2, **{"agent_params.tester_nepisodes": 2})
+    assert opt2.model_file == opt.model_name
+    sup2 = run(opt2)
+    assert [p.exitcode for *_, p in sup2.procs] == [0]
+
+
+def test_ddpg_pendulum_plumbing(tmp_root):
+    opt = opts(3, tmp_root, num_actors=2, **{"agent_params.steps": 40, "agent_params.learn_start": 30,
+                                             "agent_params.batch_size": 16})
+    sup = run(opt)
+    check_common(opt, sup, 40)
+    assert "learner/actor_loss" in {s["tag"] for s in read_scalars(opt.log_dir)}
+    assert "actor.4.weight" in load_state_dict(opt.model_name)
+
+
+def test_device_replay_per_batched_inference_and_finetune(tmp_root):
+    # device-per memory (host tensors here) fed through the shm ring, actions from the
+    # batched inference server, PER on, double DQN
+    opt = opts(4, tmp_root, num_actors=3, **{"agent_params.steps": 25, "agent_params.learn_start": 30,
+                                             "agent_params.batch_size": 8, "agent_params.enable_double": True,
+                                             "memory_params.memory_size": 256, "memory_params.ingest_ring_slots": 64,
+                                             "memory_params.ingest_chunk": 16})
+    assert opt.actor_inference == "batched" and opt.memory_params.enable_per
+    sup = run(opt)
+    check_common(opt, sup, 25)
+    # finetune: a second run starts from the first run's checkpoint (main.py:45 in the reference)
+    opt_ft = opts(1, tmp_root, timestamp="ft", model_file=opt.model_name,
+                  **{"agent_params.steps": 3, "agent_params.learn_start": 10, "agent_params.batch_size": 4,
+                     "agent_params.lr": 0.0, "memory_params.memory_size": 100})
+    run(opt_ft)
+    a, b = load_state_dict(opt.model_name), load_state_dict(opt_ft.model_name)
+    assert all(torch.equal(a[k], b[k]) for k in a)      # lr=0: weights carried over unchanged
+
+
+def test_supervisor_restarts_dead_actor(tmp_root):
+    opt = opts(6, tmp_root, inject_fault="actor:1@15", **{"agent_params.steps": 150})
+    sup = run(opt)
+    assert sup.restarts == 1
+    assert os.path.exists(opt.model_name)

@@ -1,0 +1,96 @@
+"""n-step assembler vs a brute-force oracle, using the reference author's debug
+trick (dqn_actor.py.bk-per): states carry their step index, rewards equal the
+step index, so every emitted transition can be checked by value."""
+import numpy as np
+import pytest
+
+from pytorch_distributed_amd.agents.nstep import NStepAssembler, nstep_batch_returns
+from pytorch_distributed_amd.agents.actors import actor_epsilon
+
+
+def run_episode(nstep, gamma, length, per=False):
+    asm = NStepAssembler(nstep, gamma, per)
+    asm.reset(0)
+    out = []
+    for k in range(1, length + 1):
+        term = (k == length)
+        # q(s_{k-1}) known when acting from s_{k-1}: use q = 100 + (k-1), maxq = 200 + (k-1)
+        out += [("push", k) + t for t in asm.push(action=k - 1, reward=float(k), state1=k, terminal1=term,
+                                                 qvalue=100.0 + k - 1, max_qvalue=200.0 + k - 1)]
+    out += [("flush", length) + t for t in asm.flush(max_qvalue_last=200.0 + length)]
+    return out
+
+
+def oracle(nstep, gamma, length):
+    """Expected (s0, a0, R, g, sN, term) list per SURVEY.md 3.2."""
+    exp = []
+    for k in range(2, length + 1):                 # after the k-th step, states = s_{max(0,k-n-1)}..s_k
+        first = max(0, k - (nstep + 1))
+        last = k - 1                               # lagged: end state is states[-2]
+        horizon = last - first
+        R = sum((first + 1 + i) * gamma ** i for i in range(horizon))
+        exp.append((first, first, R, gamma ** horizon, last, False))
+    # flush
+    n_states = min(length + 1, nstep + 2)
+    if n_states >= nstep + 2:
+        first = length - nstep
+    else:
+        first = 0
+    horizon = length - first
+    R = sum((first + 1 + i) * gamma ** i for i in range(horizon))
+    exp.append((first, first, R, gamma ** horizon, length, True))
+    return exp
+
+
+@pytest.mark.parametrize("nstep", [1, 3, 5])
+@pytest.mark.parametrize("length", [1, 2, 4, 9])
+def test_assembler_matches_oracle(nstep, length):
+    gamma = 0.9
+    got = run_episode(nstep, gamma, length)
+    exp = oracle(nstep, gamma, length)
+    assert len(got) == len(exp)
+    for (_, _, tr, _), e in zip(got, exp):
+        s0, a0, R, g, sN, term = tr
+        assert (s0, a0, sN, bool(term)) == (e[0], e[1], e[4], e[5])
+        assert R[0] == pytest.approx(e[2]) and g[0] == pytest.approx(e[3])
+
+
+def test_horizon_never_exceeds_nstep_in_steady_state():
+    got = run_episode(5, 0.99, 30)
+    for tag, k, tr, _ in got:
+        s0, _, _, g, sN, _ = tr
+        assert sN - s0 <= 5 and g[0] == pytest.approx(0.99 ** (sN - s0))
+
+
+def test_per_initial_priority():
+    gamma, nstep = 0.5, 2
+    got = run_episode(nstep, gamma, 6, per=True)
+    for tag, k, tr, prio in got:
+        s0, a0, R, g, sN, term = tr
+        # q0 = Q(s0, a0) = 100 + s0 ; max_q(sN) = 200 + sN
+        assert prio == pytest.approx(abs(R[0] + g[0] * (200.0 + sN) - (100.0 + s0)))
+
+
+def test_windows_do_not_straddle_episodes():
+    asm = NStepAssembler(3, 0.9)
+    asm.reset("a0")
+    asm.push(0, 1.0, "a1", True)
+    asm.flush()
+    asm.reset("b0")
+    assert asm.push(0, 1.0, "b1", False) == []
+    (tr, _), = asm.push(0, 1.0, "b2", False)
+    assert tr[0] == "b0" and tr[4] == "b1"
+
+
+def test_epsilon_ladder():
+    assert actor_epsilon(1, 1, 0.4, 7) == 0.1
+    n = 8
+    vals = [actor_epsilon(i, n, 0.4, 7) for i in range(1, n + 1)]
+    assert vals[0] == pytest.approx(0.4) and vals[-1] == pytest.approx(0.4 ** 8)
+    for i, v in enumerate(vals):
+        assert v == pytest.approx(0.4 ** (1 + 7 * i / (n - 1)))
+
+
+def test_batch_returns():
+    r, g = nstep_batch_returns(np.array([[1.0, 2.0, 3.0]]), 0.5)
+    assert r[0] == pytest.approx(1 + 1 + 0.75) and g == pytest.approx(0.125)
