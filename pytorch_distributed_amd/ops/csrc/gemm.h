@@ -1,0 +1,397 @@
+// Tiled bf16 MFMA GEMM skeleton for gfx950:  C[M,N] = sum_k A(m,k) * B(n,k)
+//
+// One template serves every matmul-shaped op in the framework -- conv forward
+// (implicit GEMM, im2col done by the A loader), conv/linear weight gradients
+// (both operands transposed, split-K, fp32 atomics into the flat gradient
+// buffer), data gradients, linear layers -- by plugging in operand *sources*
+// and an *epilogue*:
+//
+//   K-contiguous source ("N" mode): lane reads 8 consecutive k of one row with a
+//       16-byte global load, stages it [row][k] in LDS, fragments come back with
+//       ds_read_b128 exactly in the v_mfma_f32_16x16x32_bf16 A/B layout
+//       (lane l: row l&15, k = 8*(l>>4)+j).
+//   row-contiguous source ("T" mode: the reduction index is the slow axis in
+//       memory -- every weight-gradient operand): lane reads 8 consecutive ROWS at
+//       one k, stages the tile [k][row] untransposed with ds_write_b128, and
+//       fragments come back through ds_read_b64_tr_b16, CDNA4's transposing LDS
+//       read (two 4x16 blocks per fragment), so no scatter of 2-byte LDS writes.
+//
+// Block = 256 threads = 4 wave64s laid out WM x WN over a BM x BN tile, BK = 32,
+// LDS double-buffered with a register prefetch of the next k-tile, so there is
+// one barrier per k-step and the global loads of tile t+1 fly under the MFMAs of
+// tile t.  blockIdx.y = split-K slice, blockIdx.z = problem group (e.g. online
+// net on s0 and target net on s1 in ONE launch).
+#pragma once
+#include "common.h"
+
+#define GEMM_BK 32
+#define GEMM_THREADS 256
+#define GEMM_MAX_GROUPS 3
+
+// ----------------------------------------------------------------------------
+// operand sources
+// ----------------------------------------------------------------------------
+struct SrcDenseK {      // element(row, k) = p[row*ld + k]; K-contiguous
+    static constexpr bool kT = false;
+    const bf16_t* p; long ld; int rows; int red;
+    struct Ctx { const bf16_t* base; bool ok; };
+    __device__ __forceinline__ Ctx prep(int row) const { return {p + (long)row * ld, row < rows}; }
+    __device__ __forceinline__ uint4 load(const Ctx& c, int k) const {
+        if (!c.ok || k >= red) return make_uint4(0, 0, 0, 0);
+        return *reinterpret_cast<const uint4*>(c.base + k);
+    }
+};
+
+struct SrcDenseT {      // element(row, k) = p[k*ld + row]; row-contiguous
+    static constexpr bool kT = true;
+    const bf16_t* p; long ld; int rows; int red;
+    struct Ctx { const bf16_t* base; bool ok; };
+    __device__ __forceinline__ Ctx prep(int row0) const { return {p + row0, row0 < rows}; }
+    __device__ __forceinline__ uint4 load(const Ctx& c, int k) const {
+        if (!c.ok || k >= red) return make_uint4(0, 0, 0, 0);
+        return *reinterpret_cast<const uint4*>(c.base + (long)k * ld);
+    }
+};
+
+// NHWC bf16 activations viewed as im2col rows: row m = (b, oy, ox), k = (ky, kx, c)
+struct ConvGeom { int H, W, C, KH, KW, S, OH, OW; };
+
+struct SrcIm2colK {
+    static constexpr bool kT = false;
+    const bf16_t* p; ConvGeom g; int rows; int red;
+    struct Ctx { const bf16_t* base; bool ok; };
+    __device__ __forceinline__ Ctx prep(int m) const {
+        int ohw = g.OH * g.OW;
+        int b = m / ohw, r = m - b * ohw;
+        int oy = r / g.OW, ox = r - oy * g.OW;
+        return {p + (((long)b * g.H + oy * g.S) * g.W + ox * g.S) * g.C, m < rows};
+    }
+    __device__ __forceinline__ uint4 load(const Ctx& c, int k) const {
+        if (!c.ok || k >= red) return make_uint4(0, 0, 0, 0);
+        int run = g.KW * g.C;
+        int ky = k / run, off = k - ky * run;
+        return *reinterpret_cast<const uint4*>(c.base + (long)ky * g.W * g.C + off);
+    }
+};
+
+struct SrcIm2colT {     // rows = k-columns of the im2col matrix (8 consecutive), reduction = m
+    static constexpr bool kT = true;
+    const bf16_t* p; ConvGeom g; int rows; int red;
+    struct Ctx { long off; bool ok; };
+    __device__ __forceinline__ Ctx prep(int kc0) const {
+        int run = g.KW * g.C;
+        int ky = kc0 / run, off = kc0 - ky * run;
+        return {(long)ky * g.W * g.C + off, kc0 < rows};
+    }
+    __device__ __forceinline__ uint4 load(const Ctx& c, int m) const {
+        if (!c.ok || m >= red) return make_uint4(0, 0, 0, 0);
+        int ohw = g.OH * g.OW;
+        int b = m / ohw, r = m - b * ohw;
+        int oy = r / g.OW, ox = r - oy * g.OW;
+        const bf16_t* base = p + (((long)b * g.H + oy * g.S) * g.W + ox * g.S) * g.C;
+        return *reinterpret_cast<const uint4*>(base + c.off);
+    }
+};
+
+// uint8 planar frames (B rows of C*H*W bytes, gathered through idx when non-null):
+// row m = (b, oy, ox), k = (c, ky, kx) -- PyTorch's own conv-weight order, KW == 8.
+struct SrcFrameU8K {
+    static constexpr bool kT = false;
+    const uint8_t* p; const int* idx; long frame_bytes; ConvGeom g; int rows; int red;
+    struct Ctx { const uint8_t* base; bool ok; };
+    __device__ __forceinline__ Ctx prep(int m) const {
+        int ohw = g.OH * g.OW;
+        bool ok = m < rows;
+        int b = ok ? m / ohw : 0;
+        int r = m - b * ohw;
+        int oy = r / g.OW, ox = r - oy * g.OW;
+        long f = idx ? (long)idx[b] : (long)b;
+        return {p + f * frame_bytes + (long)(oy * g.S) * g.W + ox * g.S, ok};
+    }
+    __device__ __forceinline__ uint4 load(const Ctx& c, int k) const {
+        if (!c.ok || k >= red) return make_uint4(0, 0, 0, 0);
+        int khw = g.KH * g.KW;
+        int ch = k / khw, r = k - ch * khw;
+        int ky = r / g.KW;      // kx == 0: k is a multiple of 8 == KW
+        const uint8_t* src = c.base + ((long)ch * g.H + ky) * g.W;
+        uint32_t w0 = *reinterpret_cast<const uint32_t*>(src);
+        uint32_t w1 = *reinterpret_cast<const uint32_t*>(src + 4);
+        uint2 lo = u8x4_to_bf16x4(w0), hi = u8x4_to_bf16x4(w1);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+};
+
+struct SrcFrameU8T {    // rows = (c, ky, kx0..kx0+7), reduction = m
+    static constexpr bool kT = true;
+    const uint8_t* p; const int* idx; long frame_bytes; ConvGeom g; int rows; int red;
+    struct Ctx { long off; bool ok; };
+    __device__ __forceinline__ Ctx prep(int kc0) const {
+        int khw = g.KH * g.KW;
+        int ch = kc0 / khw, r = kc0 - ch * khw;
+        int ky = r / g.KW;
+        return {((long)ch * g.H + ky) * g.W, kc0 < rows};
+    }
+    __device__ __forceinline__ uint4 load(const Ctx& c, int m) const {
+        if (!c.ok || m >= red) return make_uint4(0, 0, 0, 0);
+        int ohw = g.OH * g.OW;
+        int b = m / ohw, r = m - b * ohw;
+        int oy = r / g.OW, ox = r - oy * g.OW;
+        long f = idx ? (long)idx[b] : (long)b;
+        const uint8_t* src = p + f * frame_bytes + (long)(oy * g.S) * g.W + ox * g.S + c.off;
+        uint32_t w0 = *reinterpret_cast<const uint32_t*>(src);
+        uint32_t w1 = *reinterpret_cast<const uint32_t*>(src + 4);
+        uint2 lo = u8x4_to_bf16x4(w0), hi = u8x4_to_bf16x4(w1);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+};
+
+// ----------------------------------------------------------------------------
+// epilogues: operator()(m, n, v) receives rows m..m+3 of column n
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_TANH) return tanhf(v);
+    return v;
+}
+
+struct EpiBiasAct {     // out = act(acc*scale + bias[n]) -> bf16 (and/or fp32) row-major
+    bf16_t* out; float* out32; const float* bias; float scale; int act; long ld; long ld32;
+    static constexpr bool kBiasGrad = false;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N) const {
+        if (n >= N) return;
+        float b = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (m + r < M) {
+                float x = apply_act(v[r] * scale + b, act);
+                if (out) out[(long)(m + r) * ld + n] = f2bf(x);
+                if (out32) out32[(long)(m + r) * ld32 + n] = x;
+            }
+        }
+    }
+    __device__ __forceinline__ void bias_grad(int, float, int) const {}
+};
+
+struct EpiAtomicF32 {   // split-K partial sums: atomicAdd acc into fp32 out[m*ld + n]
+    float* out; long ld; float scale;
+    static constexpr bool kBiasGrad = false;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N) const {
+        if (n >= N) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (m + r < M) atomicAdd(&out[(long)(m + r) * ld + n], v[r] * scale);
+    }
+    __device__ __forceinline__ void bias_grad(int, float, int) const {}
+};
+
+struct EpiMaskBf16 {    // dgrad: out = acc * act'(y[m][n]) -> bf16 ; y is the forward output
+    bf16_t* out; const bf16_t* y; int act; long ld; long ldy;
+    static constexpr bool kBiasGrad = false;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N) const {
+        if (n >= N) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (m + r < M) {
+                float g = v[r];
+                if (act != ACT_NONE) {
+                    float yy = bf2f(y[(long)(m + r) * ldy + n]);
+                    g = (act == ACT_RELU) ? (yy > 0.f ? g : 0.f) : g * (1.f - yy * yy);
+                }
+                out[(long)(m + r) * ld + n] = f2bf(g);
+            }
+        }
+    }
+    __device__ __forceinline__ void bias_grad(int, float, int) const {}
+};
+
+// weight gradient: atomicAdd into the flat fp32 gradient buffer in PyTorch layout.
+// GEMM col n = p*C + c (kernel layout)  ->  destination col c*P + p.
+struct EpiWgrad {
+    float* gw; float* gb; int C; int P; long ld; float scale;
+    static constexpr bool kBiasGrad = true;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N) const {
+        if (n >= N) return;
+        int p = n / C, c = n - p * C;
+        long col = (long)c * P + p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (m + r < M) atomicAdd(&gw[(long)(m + r) * ld + col], v[r] * scale);
+    }
+    __device__ __forceinline__ void bias_grad(int m, float v, int M) const {
+        if (gb && m < M) atomicAdd(&gb[m], v);
+    }
+};
+
+// ----------------------------------------------------------------------------
+// kernel
+// ----------------------------------------------------------------------------
+template <class SA, class SB, class EP>
+struct GemmGroup { SA a; SB b; EP e; int M, N, K; };
+
+template <class SA, class SB, class EP>
+struct GemmArgs { GemmGroup<SA, SB, EP> g[GEMM_MAX_GROUPS]; int ksplit; int tiles_n; };
+
+template <bool T, int ROWS>
+struct LdsShape {   // N mode: [ROWS][BK+8]; T mode: [BK][ROWS+8]
+    static constexpr int kPitch = T ? (ROWS + 8) : (GEMM_BK + 8);
+    static constexpr int kElems = T ? GEMM_BK * (ROWS + 8) : ROWS * (GEMM_BK + 8);
+};
+
+template <bool T, int ROWS, class SRC>
+struct Stager {
+    static constexpr int kItems = ROWS * GEMM_BK / 8;
+    static constexpr int kIters = (kItems + GEMM_THREADS - 1) / GEMM_THREADS;
+    typename SRC::Ctx ctx[kIters];
+    int koff[kIters];
+    int lds_off[kIters];
+    uint4 reg[kIters];
+
+    __device__ __forceinline__ void init(const SRC& s, int row0, int tid) {
+#pragma unroll
+        for (int i = 0; i < kIters; ++i) {
+            int item = tid + i * GEMM_THREADS;
+            if (!T) {
+                int r = item / (GEMM_BK / 8), kc = (item % (GEMM_BK / 8)) * 8;
+                ctx[i] = s.prep(row0 + r);
+                koff[i] = kc;
+                lds_off[i] = r * LdsShape<T, ROWS>::kPitch + kc;
+            } else {
+                int rg = item % (ROWS / 8), kk = item / (ROWS / 8);
+                ctx[i] = s.prep(row0 + rg * 8);
+                koff[i] = kk;
+                lds_off[i] = kk * LdsShape<T, ROWS>::kPitch + rg * 8;
+            }
+            if (item >= kItems) ctx[i].ok = false;
+        }
+    }
+    __device__ __forceinline__ void fetch(const SRC& s, int k0) {
+#pragma unroll
+        for (int i = 0; i < kIters; ++i) reg[i] = s.load(ctx[i], k0 + koff[i]);
+    }
+    __device__ __forceinline__ void commit(bf16_t* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < kIters; ++i)
+            if (tid + i * GEMM_THREADS < kItems) *reinterpret_cast<uint4*>(lds + lds_off[i]) = reg[i];
+    }
+};
+
+// fragment for rows r0..r0+15 (lane&15), k = 8*(lane>>4) .. +7 of the current BK=32 tile
+template <bool T, int ROWS>
+__device__ __forceinline__ bf16x8 read_frag(const bf16_t* lds, int r0, int lane) {
+    constexpr int P = LdsShape<T, ROWS>::kPitch;
+    if (!T) {
+        const bf16_t* p = lds + (r0 + (lane & 15)) * P + (lane >> 4) * 8;
+        return *reinterpret_cast<const bf16x8*>(p);
+    } else {
+        // 16-lane group g reads k = 8g..8g+7 as two 4(k) x 16(row) blocks; lane 4q+p of the
+        // group supplies the address of block row q, columns 4p..4p+3 and receives column
+        // (lane&15) of the 4 rows.
+        int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const bf16_t* p0 = lds + (8 * g + q) * P + r0 + 4 * pp;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * P));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, class SA, class SB, class EP>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs<SA, SB, EP> args) {
+    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+    static_assert(FM >= 1 && FN >= 1, "tile too small for the wave grid");
+    constexpr bool TA = SA::kT, TB = SB::kT;
+    constexpr int A_ELEMS = LdsShape<TA, BM>::kElems, B_ELEMS = LdsShape<TB, BN>::kElems;
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (A_ELEMS + B_ELEMS)];
+
+    const GemmGroup<SA, SB, EP>& G = args.g[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile_m = blockIdx.x / args.tiles_n, tile_n = blockIdx.x % args.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (m0 >= G.M || n0 >= G.N) return;     // groups may differ in size
+    int kbeg = 0, kend = G.K;
+    if (args.ksplit > 0) {
+        kbeg = blockIdx.y * args.ksplit;
+        kend = min(G.K, kbeg + args.ksplit);
+        if (kbeg >= kend) return;
+    }
+
+    Stager<TA, BM, SA> sa;
+    Stager<TB, BN, SB> sb;
+    sa.init(G.a, m0, tid);
+    sb.init(G.b, n0, tid);
+
+    f32x4 acc[FM][FN];
+    f32x4 accb[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = EP::kBiasGrad && tile_n == 0 && wn == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+
+    sa.fetch(G.a, kbeg);
+    sb.fetch(G.b, kbeg);
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
+        bf16_t* la = lds + buf * (A_ELEMS + B_ELEMS);
+        bf16_t* lb = la + A_ELEMS;
+        sa.commit(la, tid);
+        sb.commit(lb, tid);
+        __syncthreads();
+        if (k0 + GEMM_BK < kend) {      // prefetch the next k-tile under this tile's MFMAs
+            sa.fetch(G.a, k0 + GEMM_BK);
+            sb.fetch(G.b, k0 + GEMM_BK);
+        }
+        bf16x8 fa[FM], fb[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa[i] = read_frag<TA, BM>(la, wm * (BM / WM) + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb[j] = read_frag<TB, BN>(lb, wn * (BN / WN) + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+
+    // C/D layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        int m = m0 + wm * (BM / WM) + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            int n = n0 + wn * (BN / WN) + j * 16 + (lane & 15);
+            G.e(m, n, acc[i][j], G.M, G.N);
+        }
+        if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) G.e.bias_grad(m + r, accb[i][r], G.M);
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, class SA, class SB, class EP>
+static void launch_gemm(GemmArgs<SA, SB, EP>& args, int ngroups, int maxM, int maxN, int maxK, int ksplit,
+                        hipStream_t stream) {
+    int tiles_m = (maxM + BM - 1) / BM, tiles_n = (maxN + BN - 1) / BN;
+    args.tiles_n = tiles_n;
+    int nsplit = 1;
+    if (ksplit > 0) {
+        ksplit = (ksplit + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+        nsplit = (maxK + ksplit - 1) / ksplit;
+    }
+    args.ksplit = ksplit > 0 ? ksplit : 0;
+    dim3 grid(tiles_m * tiles_n, nsplit, ngroups);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, SA, SB, EP>), grid, dim3(GEMM_THREADS), 0, stream, args);
+}

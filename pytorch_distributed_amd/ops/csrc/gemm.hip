@@ -1,0 +1,216 @@
+// C-ABI entry points for the MFMA GEMM family (see gemm.h for the kernel).
+// Every function takes raw device pointers and a hipStream_t and only enqueues
+// work -- no allocation, no synchronisation -- so callers can capture whole
+// learner steps into a hipGraph.
+#include "gemm.h"
+
+namespace {
+
+ConvGeom make_geom(int H, int W, int C, int KH, int KW, int S) {
+    ConvGeom g;
+    g.H = H; g.W = W; g.C = C; g.KH = KH; g.KW = KW; g.S = S;
+    g.OH = (H - KH) / S + 1;
+    g.OW = (W - KW) / S + 1;
+    return g;
+}
+
+}  // namespace
+
+// ---- conv1 forward: uint8 planar frames (optionally gathered through idx) ----------
+// out[g][(b,oy,ox)][o] = act(scale * sum_k u8 * W[o][k] + bias[o]),  k = (c,ky,kx)
+PDA_EXPORT void pda_conv_fwd_u8(const void* const* frames, const void* const* idx, const void* const* w,
+                                const void* const* bias, void* const* out, int ngroups, int batch,
+                                int H, int W, int C, int KH, int KW, int S, int O, float scale, int act,
+                                hipStream_t stream) {
+    ConvGeom g = make_geom(H, W, C, KH, KW, S);
+    int M = batch * g.OH * g.OW, K = C * KH * KW;
+    GemmArgs<SrcFrameU8K, SrcDenseK, EpiBiasAct> a;
+    for (int i = 0; i < ngroups; ++i) {
+        a.g[i].a = {(const uint8_t*)frames[i], (const int*)idx[i], (long)C * H * W, g, M, K};
+        a.g[i].b = {(const bf16_t*)w[i], (long)K, O, K};
+        a.g[i].e = {(bf16_t*)out[i], nullptr, (const float*)bias[i], scale, act, (long)O, 0};
+        a.g[i].M = M; a.g[i].N = O; a.g[i].K = K;
+    }
+    if (O <= 32) launch_gemm<64, 32, 4, 1>(a, ngroups, M, O, K, 0, stream);
+    else launch_gemm<64, 64, 2, 2>(a, ngroups, M, O, K, 0, stream);
+}
+
+// ---- conv forward on NHWC bf16 activations; weights [O][(ky,kx,c)] bf16 ------------------
+PDA_EXPORT void pda_conv_fwd(const void* const* x, const void* const* w, const void* const* bias,
+                             void* const* out, int ngroups, int batch, int H, int W, int C, int KH, int KW,
+                             int S, int O, int act, hipStream_t stream) {
+    ConvGeom g = make_geom(H, W, C, KH, KW, S);
+    int M = batch * g.OH * g.OW, K = C * KH * KW;
+    GemmArgs<SrcIm2colK, SrcDenseK, EpiBiasAct> a;
+    for (int i = 0; i < ngroups; ++i) {
+        a.g[i].a = {(const bf16_t*)x[i], g, M, K};
+        a.g[i].b = {(const bf16_t*)w[i], (long)K, O, K};
+        a.g[i].e = {(bf16_t*)out[i], nullptr, (const float*)bias[i], 1.f, act, (long)O, 0};
+        a.g[i].M = M; a.g[i].N = O; a.g[i].K = K;
+    }
+    if (O <= 32) launch_gemm<64, 32, 4, 1>(a, ngroups, M, O, K, 0, stream);
+    else launch_gemm<64, 64, 2, 2>(a, ngroups, M, O, K, 0, stream);
+}
+
+// ---- linear forward: out = act(x[M][K] * w[N][K]^T + bias) ---------------------------------
+// ksplit > 0: split-K partial sums are atomically added into out32 (pre-zeroed, no bias/act;
+// the consumer applies them).  Otherwise bf16 and/or fp32 outputs with bias + act.
+PDA_EXPORT void pda_linear_fwd(const void* const* x, const void* const* w, const void* const* bias,
+                               void* const* out, void* const* out32, int ngroups, int M, int N, int K,
+                               long ldx, long ldw, long ldo, long ldo32, int act, int ksplit, hipStream_t stream) {
+    if (ksplit > 0) {
+        GemmArgs<SrcDenseK, SrcDenseK, EpiAtomicF32> a;
+        for (int i = 0; i < ngroups; ++i) {
+            a.g[i].a = {(const bf16_t*)x[i], ldx, M, K};
+            a.g[i].b = {(const bf16_t*)w[i], ldw, N, K};
+            a.g[i].e = {(float*)out32[i], ldo32, 1.f};
+            a.g[i].M = M; a.g[i].N = N; a.g[i].K = K;
+        }
+        launch_gemm<64, 64, 2, 2>(a, ngroups, M, N, K, ksplit, stream);
+        return;
+    }
+    GemmArgs<SrcDenseK, SrcDenseK, EpiBiasAct> a;
+    for (int i = 0; i < ngroups; ++i) {
+        a.g[i].a = {(const bf16_t*)x[i], ldx, M, K};
+        a.g[i].b = {(const bf16_t*)w[i], ldw, N, K};
+        a.g[i].e = {(bf16_t*)(out ? out[i] : nullptr), (float*)(out32 ? out32[i] : nullptr),
+                    (const float*)(bias ? bias[i] : nullptr), 1.f, act, ldo, ldo32};
+        a.g[i].M = M; a.g[i].N = N; a.g[i].K = K;
+    }
+    if (M <= 32) launch_gemm<32, 64, 1, 4>(a, ngroups, M, N, K, 0, stream);
+    else launch_gemm<64, 64, 2, 2>(a, ngroups, M, N, K, 0, stream);
+}
+
+// ---- data gradient of a linear map: dx[M][Kin] = (dy[M][Nout] * w[Nout][Kin]) * act'(y) ------
+// Also the "dcol" half of a conv data gradient (y == null: no mask).
+PDA_EXPORT void pda_linear_dgrad(const void* dy, const void* w, const void* y, void* dx, int M, int Nout, int Kin,
+                                 long lddy, long ldw, long ldy, long lddx, int act, hipStream_t stream) {
+    GemmArgs<SrcDenseK, SrcDenseT, EpiMaskBf16> a;
+    a.g[0].a = {(const bf16_t*)dy, lddy, M, Nout};
+    a.g[0].b = {(const bf16_t*)w, ldw, Kin, Nout};          // element(row=kin, red=nout) = w[nout*ldw + kin]
+    a.g[0].e = {(bf16_t*)dx, (const bf16_t*)y, y ? act : ACT_NONE, lddx, ldy};
+    a.g[0].M = M; a.g[0].N = Kin; a.g[0].K = Nout;
+    if (M <= 32) launch_gemm<32, 64, 1, 4>(a, 1, M, Kin, Nout, 0, stream);
+    else launch_gemm<64, 64, 2, 2>(a, 1, M, Kin, Nout, 0, stream);
+}
+
+// ---- weight gradient of a linear map: gw[Nout][perm(Kin)] += dy^T[Nout][B] * x[B][Kin] --------
+PDA_EXPORT void pda_linear_wgrad(const void* dy, const void* x, void* gw, void* gb, int B, int Nout, int Kin,
+                                 long lddy, long ldx, long ldg, int C, int P, float scale, int ksplit,
+                                 hipStream_t stream) {
+    GemmArgs<SrcDenseT, SrcDenseT, EpiWgrad> a;
+    a.g[0].a = {(const bf16_t*)dy, lddy, Nout, B};
+    a.g[0].b = {(const bf16_t*)x, ldx, Kin, B};
+    a.g[0].e = {(float*)gw, (float*)gb, C, P, ldg, scale};
+    a.g[0].M = Nout; a.g[0].N = Kin; a.g[0].K = B;
+    if (Nout <= 32) launch_gemm<32, 64, 1, 4>(a, 1, Nout, Kin, B, ksplit, stream);
+    else launch_gemm<64, 64, 2, 2>(a, 1, Nout, Kin, B, ksplit, stream);
+}
+
+// ---- conv weight gradient, NHWC bf16 input: gw[O][c][ky][kx] += sum_m dy[m][o] * im2col(x)[m][k] ---
+PDA_EXPORT void pda_conv_wgrad(const void* dy, const void* x, void* gw, void* gb, int batch, int H, int W, int C,
+                               int KH, int KW, int S, int O, int ksplit, hipStream_t stream) {
+    ConvGeom g = make_geom(H, W, C, KH, KW, S);
+    int M = batch * g.OH * g.OW, K = C * KH * KW;
+    GemmArgs<SrcDenseT, SrcIm2colT, EpiWgrad> a;
+    a.g[0].a = {(const bf16_t*)dy, (long)O, O, M};
+    a.g[0].b = {(const bf16_t*)x, g, K, M};
+    a.g[0].e = {(float*)gw, (float*)gb, C, KH * KW, (long)K, 1.f};
+    a.g[0].M = O; a.g[0].N = K; a.g[0].K = M;
+    if (O <= 32) launch_gemm<32, 64, 1, 4>(a, 1, O, K, M, ksplit, stream);
+    else launch_gemm<64, 64, 2, 2>(a, 1, O, K, M, ksplit, stream);
+}
+
+// ---- conv1 weight gradient from uint8 frames (k order (c,ky,kx) == PyTorch's) ----------------------
+PDA_EXPORT void pda_conv_wgrad_u8(const void* dy, const void* frames, const void* idx, void* gw, void* gb,
+                                  int batch, int H, int W, int C, int KH, int KW, int S, int O, float scale,
+                                  int ksplit, hipStream_t stream) {
+    ConvGeom g = make_geom(H, W, C, KH, KW, S);
+    int M = batch * g.OH * g.OW, K = C * KH * KW;
+    GemmArgs<SrcDenseT, SrcFrameU8T, EpiWgrad> a;
+    a.g[0].a = {(const bf16_t*)dy, (long)O, O, M};
+    a.g[0].b = {(const uint8_t*)frames, (const int*)idx, (long)C * H * W, g, K, M};
+    a.g[0].e = {(float*)gw, (float*)gb, 1, K, (long)K, scale};   // C=1,P=K: identity column map
+    a.g[0].M = O; a.g[0].N = K; a.g[0].K = M;
+    if (O <= 32) launch_gemm<32, 64, 1, 4>(a, 1, O, K, M, ksplit, stream);
+    else launch_gemm<64, 64, 2, 2>(a, 1, O, K, M, ksplit, stream);
+}
+
+// ---- col2im: fold dcol[(b,oy,ox)][(ky,kx,c)] back onto the NHWC input grid, times act'(y_in) -----
+__global__ void col2im_kernel(const bf16_t* __restrict__ dcol, const bf16_t* __restrict__ yin,
+                              bf16_t* __restrict__ dx, ConvGeom g, int batch, int act) {
+    // one thread = 8 channels of one input pixel
+    int cg = g.C / 8;
+    long total = (long)batch * g.H * g.W * cg;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int c8 = (int)(t % cg);
+    long pix = t / cg;
+    int ix = (int)(pix % g.W);
+    long r = pix / g.W;
+    int iy = (int)(r % g.H);
+    int b = (int)(r / g.H);
+    int K = g.KH * g.KW * g.C;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int ky = iy % g.S; ky < g.KH; ky += g.S) {
+        int oy = (iy - ky) / g.S;
+        if (iy - ky < 0) break;
+        if (oy >= g.OH) continue;
+        for (int kx = ix % g.S; kx < g.KW; kx += g.S) {
+            int ox = (ix - kx) / g.S;
+            if (ix - kx < 0) break;
+            if (ox >= g.OW) continue;
+            const bf16_t* src = dcol + ((long)(b * g.OH + oy) * g.OW + ox) * K + (ky * g.KW + kx) * g.C + c8 * 8;
+            uint4 v = *reinterpret_cast<const uint4*>(src);
+            const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += bf2f(e[i]);
+        }
+    }
+    long o = pix * g.C + c8 * 8;
+    uint4 yv = *reinterpret_cast<const uint4*>(yin + o);
+    const bf16_t* ye = reinterpret_cast<const bf16_t*>(&yv);
+    uint32_t outw[4];
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        float g0 = acc[i], g1 = acc[i + 1];
+        float y0 = bf2f(ye[i]), y1 = bf2f(ye[i + 1]);
+        if (act == ACT_RELU) { g0 = y0 > 0.f ? g0 : 0.f; g1 = y1 > 0.f ? g1 : 0.f; }
+        else if (act == ACT_TANH) { g0 *= (1.f - y0 * y0); g1 *= (1.f - y1 * y1); }
+        outw[i / 2] = pack2bf(g0, g1);
+    }
+    *reinterpret_cast<uint4*>(dx + o) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+}
+
+PDA_EXPORT void pda_col2im(const void* dcol, const void* yin, void* dx, int batch, int H, int W, int C, int KH,
+                           int KW, int S, int act, hipStream_t stream) {
+    ConvGeom g = make_geom(H, W, C, KH, KW, S);
+    long total = (long)batch * H * W * (C / 8);
+    int threads = 256;
+    long blocks = (total + threads - 1) / threads;
+    hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream, (const bf16_t*)dcol,
+                       (const bf16_t*)yin, (bf16_t*)dx, g, batch, act);
+}
+
+// ---- probe: returns what ds_read_b64_tr_b16 delivers for a known LDS image (unit-tested on the GPU) --
+__global__ void tr_probe_kernel(int* out) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[32 * 72];
+    for (int i = threadIdx.x; i < 32 * 72; i += blockDim.x) lds[i] = (bf16_t)i;
+    __syncthreads();
+    int lane = threadIdx.x & 63;
+    // same addressing as read_frag<true, 64>: pitch 72, r0 = 0
+    int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const bf16_t* p0 = lds + (8 * g + q) * 72 + 4 * pp;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * 72));
+    for (int i = 0; i < 4; ++i) {
+        out[lane * 8 + i] = (unsigned short)lo[i];
+        out[lane * 8 + 4 + i] = (unsigned short)hi[i];
+    }
+}
+PDA_EXPORT void pda_tr_probe(void* out, hipStream_t stream) {
+    hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, stream, (int*)out);
+}

@@ -1,0 +1,175 @@
+// Prioritized-replay segment tree (radix 64 = one child per wavefront lane) and
+// HBM replay data movement.
+#include "common.h"
+
+#define RADIX 64
+
+// ---- leaves: tree[idx[i]] = value[i] for both trees ---------------------------------
+__global__ void segtree_set_leaves_kernel(float* sum, float* mn, const int* idx, const float* val, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        int leaf = idx[i];
+        float v = val[i];
+        sum[leaf] = v;
+        mn[leaf] = v;
+    }
+}
+PDA_EXPORT void pda_segtree_set_leaves(void* sum, void* mn, const void* idx, const void* val, int n,
+                                       hipStream_t stream) {
+    hipLaunchKernelGGL(segtree_set_leaves_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (float*)sum,
+                       (float*)mn, (const int*)idx, (const float*)val, n);
+}
+
+// ---- repair one level: for each touched leaf, one wave recomputes its level-`lvl`
+// ancestor from that ancestor's 64 children (idempotent on duplicates, no atomics) ----
+__global__ __launch_bounds__(256) void segtree_repair_kernel(float* sum, float* mn, const int* idx, int n,
+                                                             int child_off, int parent_off, int shift) {
+    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n) return;
+    int node = idx[wave] >> shift;              // ancestor index within its level (shift = 6 * lvl)
+    long child = (long)child_off + (long)node * RADIX + lane;
+    float s = wave_sum(sum[child]);
+    float m = wave_min(mn[child]);
+    if (lane == 0) {
+        sum[parent_off + node] = s;
+        mn[parent_off + node] = m;
+    }
+}
+PDA_EXPORT void pda_segtree_repair_level(void* sum, void* mn, const void* idx, int n, int child_off,
+                                         int parent_off, int lvl, hipStream_t stream) {
+    long threads = (long)n * 64;
+    hipLaunchKernelGGL(segtree_repair_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
+                       (float*)sum, (float*)mn, (const int*)idx, n, child_off, parent_off, 6 * lvl);
+}
+
+// ---- stratified prefix-sum sampling: one wave per sample ---------------------------------
+struct TreeOffsets { int off[8]; };
+
+__global__ __launch_bounds__(256) void segtree_sample_kernel(const float* __restrict__ sum,
+                                                             const float* __restrict__ mn, TreeOffsets offs,
+                                                             int depth, int num_leaves,
+                                                             const float* __restrict__ uniforms, int B, float beta,
+                                                             int* __restrict__ out_idx, float* __restrict__ out_w) {
+    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B) return;
+    int top = offs.off[depth - 1];
+    float kid = sum[top + lane];
+    float total = wave_sum(kid);
+    float pmin = wave_min(mn[top + lane]);
+    float v = ((float)wave + uniforms[wave]) / (float)B * total;
+    int node = 0;
+    for (int lvl = depth - 1; lvl >= 0; --lvl) {
+        if (lvl != depth - 1) kid = sum[(long)offs.off[lvl] + (long)node * RADIX + lane];
+        float incl = wave_scan_incl(kid, lane);
+        bool hit = (incl >= v) && (kid > 0.f);
+        unsigned long long mask = __ballot(hit);
+        int pick;
+        if (mask) {
+            pick = __ffsll((long long)mask) - 1;
+        } else {                                    // rounding pushed v past the end: last positive child
+            unsigned long long pos = __ballot(kid > 0.f);
+            pick = pos ? 63 - __clzll((long long)pos) : 0;
+        }
+        float excl = __shfl(incl - kid, pick, 64);
+        v -= excl;
+        node = node * RADIX + pick;
+    }
+    node = min(node, num_leaves - 1);
+    if (lane == 0) {
+        float p = sum[node];
+        out_idx[wave] = node;
+        out_w[wave] = __powf(pmin / fmaxf(p, 1e-30f), beta);
+    }
+}
+PDA_EXPORT void pda_segtree_sample(const void* sum, const void* mn, const int* offs, int depth, int num_leaves,
+                                   const void* uniforms, int B, float beta, void* out_idx, void* out_w,
+                                   hipStream_t stream) {
+    TreeOffsets o;
+    for (int i = 0; i < 8; ++i) o.off[i] = offs[i];
+    long threads = (long)B * 64;
+    hipLaunchKernelGGL(segtree_sample_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)sum, (const float*)mn, o, depth, num_leaves, (const float*)uniforms, B, beta,
+                       (int*)out_idx, (float*)out_w);
+}
+
+// uniform index draw on device (counter-based, graph-replayable: the counter lives in memory)
+__global__ void uniform_idx_kernel(int* out_idx, float* out_w, int B, const int* size, unsigned long long seed,
+                                   unsigned long long* counter) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long ctr = *counter;
+    if (i < B) {
+        int n = max(*size, 1);
+        uint32_t r = hash_u32(seed ^ (ctr * 0x9e3779b97f4a7c15ULL + (unsigned long long)i + 1));
+        out_idx[i] = (int)(((unsigned long long)r * (unsigned long long)n) >> 32);
+        if (out_w) out_w[i] = 1.f;
+    }
+}
+__global__ void counter_tick_kernel(unsigned long long* counter) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1;
+}
+PDA_EXPORT void pda_uniform_idx(void* out_idx, void* out_w, int B, const void* size, unsigned long long seed,
+                                void* counter, hipStream_t stream) {
+    hipLaunchKernelGGL(uniform_idx_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, (int*)out_idx,
+                       (float*)out_w, B, (const int*)size, seed, (unsigned long long*)counter);
+    hipLaunchKernelGGL(counter_tick_kernel, dim3(1), dim3(64), 0, stream, (unsigned long long*)counter);
+}
+// uniforms[i] in [0,1) for the stratified sampler, same counter scheme
+__global__ void uniform_f32_kernel(float* out, int B, unsigned long long seed, unsigned long long* counter) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long ctr = *counter;
+    if (i < B) out[i] = u01(hash_u32(seed ^ (ctr * 0x9e3779b97f4a7c15ULL + (unsigned long long)i + 1)));
+}
+PDA_EXPORT void pda_uniform_f32(void* out, int B, unsigned long long seed, void* counter, hipStream_t stream) {
+    hipLaunchKernelGGL(uniform_f32_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, (float*)out, B, seed,
+                       (unsigned long long*)counter);
+    hipLaunchKernelGGL(counter_tick_kernel, dim3(1), dim3(64), 0, stream, (unsigned long long*)counter);
+}
+
+// ---- replay: unpack packed transition records into the ring buffers -------------------------
+// One workgroup per record: 16-byte vector copies of both states, then the float tail.
+__global__ __launch_bounds__(256) void replay_unpack_kernel(const uint8_t* __restrict__ rec, long rec_stride,
+                                                            const int* __restrict__ pos,
+                                                            uint8_t* __restrict__ s0, uint8_t* __restrict__ s1,
+                                                            int state_bytes, int state_stride,
+                                                            float* __restrict__ tails, int tail_ld, int tail_floats) {
+    int r = blockIdx.x;
+    const uint8_t* src = rec + (long)r * rec_stride;
+    long dst_row = (long)pos[r] * state_bytes;
+    int vec = state_bytes / 16;
+    const uint4* a = reinterpret_cast<const uint4*>(src);
+    const uint4* b = reinterpret_cast<const uint4*>(src + state_stride);
+    uint4* d0 = reinterpret_cast<uint4*>(s0 + dst_row);
+    uint4* d1 = reinterpret_cast<uint4*>(s1 + dst_row);
+    if (state_bytes % 16 == 0 && dst_row % 16 == 0) {
+        for (int i = threadIdx.x; i < vec; i += blockDim.x) { d0[i] = a[i]; d1[i] = b[i]; }
+    } else {
+        for (int i = threadIdx.x; i < state_bytes; i += blockDim.x) {
+            s0[dst_row + i] = src[i];
+            s1[dst_row + i] = src[state_stride + i];
+        }
+    }
+    const float* tl = reinterpret_cast<const float*>(src + 2 * (long)state_stride);
+    if (threadIdx.x < tail_floats) tails[(long)pos[r] * tail_ld + threadIdx.x] = tl[threadIdx.x];
+}
+PDA_EXPORT void pda_replay_unpack(const void* rec, long rec_stride, int n, const void* pos, void* s0, void* s1,
+                                  int state_bytes, int state_stride, void* tails, int tail_ld, int tail_floats,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(replay_unpack_kernel, dim3(n), dim3(256), 0, stream, (const uint8_t*)rec, rec_stride,
+                       (const int*)pos, (uint8_t*)s0, (uint8_t*)s1, state_bytes, state_stride, (float*)tails,
+                       tail_ld, tail_floats);
+}
+
+// ---- replay: gather B rows of row_bytes (multiple of 16) ------------------------------------------
+__global__ __launch_bounds__(256) void replay_gather_kernel(const uint8_t* __restrict__ src,
+                                                            const int* __restrict__ idx, int row_bytes,
+                                                            uint8_t* __restrict__ out) {
+    int r = blockIdx.x;
+    const uint4* a = reinterpret_cast<const uint4*>(src + (long)idx[r] * row_bytes);
+    uint4* d = reinterpret_cast<uint4*>(out + (long)r * row_bytes);
+    for (int i = threadIdx.x; i < row_bytes / 16; i += blockDim.x) d[i] = a[i];
+}
+PDA_EXPORT void pda_replay_gather(const void* src, const void* idx, int B, int row_bytes, void* out,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(replay_gather_kernel, dim3(B), dim3(256), 0, stream, (const uint8_t*)src, (const int*)idx,
+                       row_bytes, (uint8_t*)out);
+}

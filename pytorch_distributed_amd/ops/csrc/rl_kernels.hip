@@ -1,0 +1,323 @@
+// RL-specific fused kernels: DQN head (fc2 + n-step TD target + loss + dQ +
+// priorities), critic TD for DDPG, fused Adam / Polyak over flat buffers with
+// bf16 shadow-weight emission, epsilon-greedy actor epilogue.
+#include "common.h"
+
+// ----------------------------------------------------------------------------
+// DQN head.  One wave64 per sample; the 512-wide hidden row is 8 values per lane.
+//   h      = relu(h1pre + b4)                    (fc1 split-K sums arrive as fp32)
+//   q      = W5 h + b5                           (fp32 master weights, A <= 32 actions)
+//   y      = r + gamma^n * max_a q_tgt(s_n)[a] * (1 - done)      (double: a* from online(s_n))
+//   loss  += w (q[a] - y)^2 / B,   dq[a] = 2 w (q[a]-y) / B
+//   dh1    = dq[a] * W5[a,:] * (h > 0)           -> bf16, feeds fc1 wgrad/dgrad
+//   leaf   = (|q[a]-y| + eps)^alpha              -> written straight into the sum/min tree leaves
+// The fp32 split-K buffers are zeroed after reading so the next step can
+// accumulate into them again without a memset node.
+// ----------------------------------------------------------------------------
+struct DqnHeadArgs {
+    float* h1pre_on0; float* h1pre_tg1; float* h1pre_on1;   // [B][HID]; on1 may be null (no double-DQN)
+    const float* b4_on; const float* b4_tg;
+    const float* w5_on; const float* b5_on; const float* w5_tg; const float* b5_tg;
+    const float* tails; int tail_ld; int off_action, off_reward, off_gamma, off_term;
+    const int* idx; const float* isw;                        // sampled replay rows, importance weights (may be null)
+    bf16_t* h1_on0; bf16_t* dh1; bf16_t* dq; int dq_ld;      // outputs
+    float* q_out; float* td_out; float* loss_sum;
+    float* leaf_sum; float* leaf_min; float prio_eps, prio_alpha;
+    int B, HID, A;
+};
+
+template <int HID>
+__global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
+    constexpr int PER = HID / 64;       // values per lane (8 for 512)
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int b = blockIdx.x * 4 + wave;
+    if (b >= p.B) return;
+    long row = (long)b * HID + lane * PER;
+
+    float h0[PER], ht[PER], hd[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        h0[j] = fmaxf(p.h1pre_on0[row + j] + p.b4_on[lane * PER + j], 0.f);
+        ht[j] = fmaxf(p.h1pre_tg1[row + j] + p.b4_tg[lane * PER + j], 0.f);
+        hd[j] = p.h1pre_on1 ? fmaxf(p.h1pre_on1[row + j] + p.b4_on[lane * PER + j], 0.f) : 0.f;
+        p.h1pre_on0[row + j] = 0.f;
+        p.h1pre_tg1[row + j] = 0.f;
+        if (p.h1pre_on1) p.h1pre_on1[row + j] = 0.f;
+    }
+
+    // lane a keeps q(.)[a]: no runtime-indexed arrays (they would live in scratch)
+    float myq0 = 0.f, myqt = 0.f, best_t = -INFINITY, best_d = -INFINITY;
+    int arg_d = 0;
+    for (int a = 0; a < p.A; ++a) {
+        float s0 = 0.f, st = 0.f, sd = 0.f;
+        const float* w_on = p.w5_on + (long)a * HID + lane * PER;
+        const float* w_tg = p.w5_tg + (long)a * HID + lane * PER;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            s0 += h0[j] * w_on[j];
+            st += ht[j] * w_tg[j];
+            sd += hd[j] * w_on[j];
+        }
+        s0 = wave_sum(s0) + p.b5_on[a];
+        st = wave_sum(st) + p.b5_tg[a];
+        sd = wave_sum(sd) + p.b5_on[a];
+        if (lane == a) { myq0 = s0; myqt = st; }
+        best_t = fmaxf(best_t, st);
+        if (sd > best_d) { best_d = sd; arg_d = a; }
+    }
+    float next_q = p.h1pre_on1 ? __shfl(myqt, arg_d, 64) : best_t;
+
+    int ridx = p.idx ? p.idx[b] : b;
+    const float* tl = p.tails + (long)ridx * p.tail_ld;
+    int act = (int)tl[p.off_action];
+    act = min(max(act, 0), p.A - 1);
+    float y = tl[p.off_reward] + tl[p.off_gamma] * next_q * (1.f - tl[p.off_term]);
+    float td = __shfl(myq0, act, 64) - y;
+    float w = p.isw ? p.isw[b] : 1.f;
+    float dqa = 2.f * w * td / (float)p.B;
+
+    const float* w_act = p.w5_on + (long)act * HID + lane * PER;
+    uint32_t hw[PER / 2], dw[PER / 2];
+#pragma unroll
+    for (int j = 0; j < PER; j += 2) {
+        hw[j / 2] = pack2bf(h0[j], h0[j + 1]);
+        dw[j / 2] = pack2bf(h0[j] > 0.f ? dqa * w_act[j] : 0.f, h0[j + 1] > 0.f ? dqa * w_act[j + 1] : 0.f);
+    }
+    uint32_t* ho = reinterpret_cast<uint32_t*>(p.h1_on0 + row);
+    uint32_t* dout = reinterpret_cast<uint32_t*>(p.dh1 + row);
+#pragma unroll
+    for (int j = 0; j < PER / 2; ++j) { ho[j] = hw[j]; dout[j] = dw[j]; }
+
+    if (lane < p.dq_ld) p.dq[(long)b * p.dq_ld + lane] = f2bf(lane == act ? dqa : 0.f);
+    if (lane < p.A && p.q_out) p.q_out[(long)b * p.A + lane] = myq0;
+    if (lane == 0) {
+        if (p.td_out) p.td_out[b] = td;
+        atomicAdd(p.loss_sum, w * td * td / (float)p.B);
+        if (p.leaf_sum) {
+            float leaf = __powf(fabsf(td) + p.prio_eps, p.prio_alpha);
+            p.leaf_sum[ridx] = leaf;
+            p.leaf_min[ridx] = leaf;
+        }
+    }
+}
+
+PDA_EXPORT void pda_dqn_head(const DqnHeadArgs* args, hipStream_t stream) {
+    DqnHeadArgs p = *args;
+    dim3 grid((p.B + 3) / 4), block(256);
+    if (p.HID == 512) hipLaunchKernelGGL(dqn_head_kernel<512>, grid, block, 0, stream, p);
+    else if (p.HID == 256) hipLaunchKernelGGL(dqn_head_kernel<256>, grid, block, 0, stream, p);
+}
+
+// forward-only head for the actor server: q = W5 relu(h1pre + b4) + b5, then epsilon-greedy
+struct ActHeadArgs {
+    float* h1pre; const float* b4; const float* w5; const float* b5;
+    const float* eps; float* out; int out_ld;        // out[b] = {action, q[action], max q}
+    float* q_out; int B, HID, A; unsigned long long seed; const unsigned long long* counter;
+};
+
+template <int HID>
+__global__ __launch_bounds__(256) void act_head_kernel(ActHeadArgs p) {
+    constexpr int PER = HID / 64;
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int b = blockIdx.x * 4 + wave;
+    if (b >= p.B) return;
+    long row = (long)b * HID + lane * PER;
+    float h[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        h[j] = fmaxf(p.h1pre[row + j] + p.b4[lane * PER + j], 0.f);
+        p.h1pre[row + j] = 0.f;
+    }
+    float best = -INFINITY, myq = 0.f;
+    int arg = 0;
+    for (int a = 0; a < p.A; ++a) {
+        float s = 0.f;
+        const float* w = p.w5 + (long)a * HID + lane * PER;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) s += h[j] * w[j];
+        s = wave_sum(s) + p.b5[a];
+        if (lane == a) myq = s;
+        if (s > best) { best = s; arg = a; }
+    }
+    if (lane < p.A && p.q_out) p.q_out[(long)b * p.A + lane] = myq;
+    unsigned long long ctr = p.counter ? *p.counter : 0ull;
+    uint32_t r0 = hash_u32(p.seed ^ (ctr * 0x9e3779b97f4a7c15ULL + (unsigned long long)b * 2 + 1));
+    uint32_t r1 = hash_u32(p.seed ^ (ctr * 0x9e3779b97f4a7c15ULL + (unsigned long long)b * 2 + 2));
+    int action = arg;
+    float e = p.eps ? p.eps[b] : 0.f;
+    if (e > 0.f && u01(r0) < e) action = (int)(r1 % (uint32_t)p.A);
+    float q_action = __shfl(myq, action, 64);
+    if (lane == 0) {
+        float* o = p.out + (long)b * p.out_ld;
+        o[0] = (float)action;
+        o[1] = q_action;
+        o[2] = best;
+    }
+}
+
+PDA_EXPORT void pda_act_head(const ActHeadArgs* args, hipStream_t stream) {
+    ActHeadArgs p = *args;
+    dim3 grid((p.B + 3) / 4), block(256);
+    if (p.HID == 512) hipLaunchKernelGGL(act_head_kernel<512>, grid, block, 0, stream, p);
+    else if (p.HID == 256) hipLaunchKernelGGL(act_head_kernel<256>, grid, block, 0, stream, p);
+}
+
+// ----------------------------------------------------------------------------
+// generic n-step TD for value heads given as vectors (DDPG critic, MLP DQN):
+//   y = r + gamma^n * next_q * (1 - done);  td = q - y;  dq = 2 w td / B
+// ----------------------------------------------------------------------------
+__global__ void td_vector_kernel(const float* q, const float* next_q, const float* tails, int tail_ld,
+                                 int off_reward, int off_gamma, int off_term, const int* idx, const float* isw,
+                                 float* dq, float* td_out, float* loss_sum, float* leaf_sum, float* leaf_min,
+                                 float prio_eps, float prio_alpha, int B) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    float contrib = 0.f;
+    if (b < B) {
+        int ridx = idx ? idx[b] : b;
+        const float* tl = tails + (long)ridx * tail_ld;
+        float y = tl[off_reward] + tl[off_gamma] * next_q[b] * (1.f - tl[off_term]);
+        float td = q[b] - y;
+        float w = isw ? isw[b] : 1.f;
+        dq[b] = 2.f * w * td / (float)B;
+        if (td_out) td_out[b] = td;
+        contrib = w * td * td / (float)B;
+        if (leaf_sum) {
+            float leaf = __powf(fabsf(td) + prio_eps, prio_alpha);
+            leaf_sum[ridx] = leaf;
+            leaf_min[ridx] = leaf;
+        }
+    }
+    contrib = wave_sum(contrib);
+    if ((threadIdx.x & 63) == 0 && contrib != 0.f) atomicAdd(loss_sum, contrib);
+}
+
+PDA_EXPORT void pda_td_vector(const void* q, const void* next_q, const void* tails, int tail_ld, int off_reward,
+                              int off_gamma, int off_term, const void* idx, const void* isw, void* dq, void* td_out,
+                              void* loss_sum, void* leaf_sum, void* leaf_min, float prio_eps, float prio_alpha,
+                              int B, hipStream_t stream) {
+    hipLaunchKernelGGL(td_vector_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, (const float*)q,
+                       (const float*)next_q, (const float*)tails, tail_ld, off_reward, off_gamma, off_term,
+                       (const int*)idx, (const float*)isw, (float*)dq, (float*)td_out, (float*)loss_sum,
+                       (float*)leaf_sum, (float*)leaf_min, prio_eps, prio_alpha, B);
+}
+
+// ----------------------------------------------------------------------------
+// flat-buffer optimizer.  One launch updates every parameter, clips the gradient
+// by value, zeroes it for the next accumulation and emits the bf16 "shadow"
+// weights in the layout the MFMA kernels read ([row][p*C + c], padded pitch).
+// Segment table entry (8 ints): start, count, cols, C, P, shadow_off, shadow_ld, flags(1 = has shadow)
+// hyper (device floats): lr, beta1, beta2, eps, weight_decay, clip, grad_scale
+// ----------------------------------------------------------------------------
+struct SegEntry { int start, count, cols, C, P, shadow_off, shadow_ld, flags; };
+
+__device__ __forceinline__ void shadow_store(bf16_t* shadow, const SegEntry& s, int e, float v) {
+    if (!(s.flags & 1)) return;
+    int row = e / s.cols, col = e - row * s.cols;
+    int c = col / s.P, pp = col - c * s.P;
+    shadow[(long)s.shadow_off + (long)row * s.shadow_ld + pp * s.C + c] = f2bf(v);
+}
+
+#define OPT_CHUNK 2048      // elements per block
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   bf16_t* __restrict__ shadow, const SegEntry* __restrict__ segs,
+                                                   const int2* __restrict__ chunks, const float* __restrict__ hyper,
+                                                   const int* __restrict__ step) {
+    int2 ch = chunks[blockIdx.x];           // (segment, first element within the segment)
+    SegEntry s = segs[ch.x];
+    float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], clip = hyper[5],
+          gscale = hyper[6];
+    float t = (float)(*step + 1);
+    float bc1 = 1.f - __powf(b1, t), bc2 = 1.f - __powf(b2, t);
+    float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+    int end = min(ch.y + OPT_CHUNK, s.count);
+    for (int e = ch.y + threadIdx.x; e < end; e += 256) {
+        long i = (long)s.start + e;
+        float gi = g[i] * gscale;
+        gi = fminf(fmaxf(gi, -clip), clip);
+        float pi = p[i];
+        gi += wd * pi;
+        float mi = b1 * m[i] + (1.f - b1) * gi;
+        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        p[i] = pi; m[i] = mi; v[i] = vi; g[i] = 0.f;
+        shadow_store(shadow, s, e, pi);
+    }
+}
+
+__global__ void tick_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
+
+PDA_EXPORT void pda_adam(void* p, void* g, void* m, void* v, void* shadow, const void* segs, const void* chunks,
+                         int nchunks, const void* hyper, void* step, hipStream_t stream) {
+    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, stream, (float*)p, (float*)g, (float*)m, (float*)v,
+                       (bf16_t*)shadow, (const SegEntry*)segs, (const int2*)chunks, (const float*)hyper,
+                       (const int*)step);
+    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, stream, (int*)step);
+}
+
+// tgt = (1 - tau) tgt + tau src (tau = 1: hard copy), with the target's shadow weights
+__global__ __launch_bounds__(256) void polyak_kernel(float* __restrict__ tgt, const float* __restrict__ src,
+                                                     bf16_t* __restrict__ shadow, const SegEntry* __restrict__ segs,
+                                                     const int2* __restrict__ chunks, float tau) {
+    int2 ch = chunks[blockIdx.x];
+    SegEntry s = segs[ch.x];
+    int end = min(ch.y + OPT_CHUNK, s.count);
+    for (int e = ch.y + threadIdx.x; e < end; e += 256) {
+        long i = (long)s.start + e;
+        float t = tgt[i] + tau * (src[i] - tgt[i]);
+        if (tau >= 1.f) t = src[i];
+        tgt[i] = t;
+        if (shadow) shadow_store(shadow, s, e, t);
+    }
+}
+
+PDA_EXPORT void pda_polyak(void* tgt, const void* src, void* shadow, const void* segs, const void* chunks,
+                           int nchunks, float tau, hipStream_t stream) {
+    hipLaunchKernelGGL(polyak_kernel, dim3(nchunks), dim3(256), 0, stream, (float*)tgt, (const float*)src,
+                       (bf16_t*)shadow, (const SegEntry*)segs, (const int2*)chunks, tau);
+}
+
+// plain multi-tensor Polyak over a flat fp32 buffer (no shadow): used by utils.helpers
+__global__ void polyak_flat_kernel(float* tgt, const float* src, long n, float tau) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) tgt[i] += tau * (src[i] - tgt[i]);
+}
+PDA_EXPORT void pda_polyak_flat(void* tgt, const void* src, long n, float tau, hipStream_t stream) {
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(polyak_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (float*)tgt,
+                       (const float*)src, n, tau);
+}
+
+// elementwise helpers for the MLP engines ---------------------------------------------------
+// out_bf16[i] = bf16(in_f32[i]) over a [rows][cols] block with pitches (pads untouched)
+__global__ void f32_to_bf16_kernel(const float* in, long ld_in, bf16_t* out, long ld_out, int rows, int cols) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)rows * cols) return;
+    int r = (int)(t / cols), c = (int)(t - (long)r * cols);
+    out[(long)r * ld_out + c] = f2bf(in[(long)r * ld_in + c]);
+}
+PDA_EXPORT void pda_f32_to_bf16(const void* in, long ld_in, void* out, long ld_out, int rows, int cols,
+                                hipStream_t stream) {
+    long total = (long)rows * cols;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)in, ld_in, (bf16_t*)out, ld_out, rows, cols);
+}
+
+// gather float state rows (replay, fp32 [M][D]) through idx into a padded bf16 matrix [B][ld]
+__global__ void gather_rows_bf16_kernel(const float* src, long ld_src, const int* idx, bf16_t* out, long ld_out,
+                                        int B, int D) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)B * D) return;
+    int b = (int)(t / D), d = (int)(t - (long)b * D);
+    int r = idx ? idx[b] : b;
+    out[(long)b * ld_out + d] = f2bf(src[(long)r * ld_src + d]);
+}
+PDA_EXPORT void pda_gather_rows_bf16(const void* src, long ld_src, const void* idx, void* out, long ld_out, int B,
+                                     int D, hipStream_t stream) {
+    long total = (long)B * D;
+    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)src, ld_src, (const int*)idx, (bf16_t*)out, ld_out, B, D);
+}

@@ -1,0 +1,138 @@
+"""ctypes bindings for the MFMA GEMM family (csrc/gemm.hip) and small helpers.
+
+All functions enqueue on torch's current HIP stream and allocate nothing, so
+they are safe inside torch.cuda.graph() capture.  Tensors are passed as raw
+device pointers; shapes/pitches are explicit because activations are bf16 NHWC
+buffers owned by the engines, not autograd tensors.
+
+Layouts
+  activations   bf16, NHWC flattened to [rows = (b, y, x)][channels]
+  conv weights  bf16 "shadow" copies [O][(ky, kx, c)]  (conv1: [O][(c, ky, kx)] = PyTorch's)
+  fc weights    bf16 [N][K], K permuted to the NHWC flatten order where needed
+  gradients     fp32, written in PyTorch's own parameter layout (atomicAdd)
+"""
+import ctypes
+
+import torch
+
+from . import lib
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+BF16 = torch.bfloat16
+
+_vp = ctypes.c_void_p
+
+
+def _ptr(t):
+    return _vp(t.data_ptr()) if t is not None else _vp(0)
+
+
+def _arr(ts):
+    return (_vp * len(ts))(*[(t.data_ptr() if t is not None else 0) for t in ts])
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+_configured = False
+
+
+def _L():
+    global _configured
+    L = lib()
+    if not _configured:
+        c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
+        L.pda_conv_fwd_u8.argtypes = [_vp] * 5 + [c_int] * 9 + [c_float, c_int, _vp]
+        L.pda_conv_fwd.argtypes = [_vp] * 4 + [c_int] * 10 + [_vp]
+        L.pda_linear_fwd.argtypes = [_vp] * 5 + [c_int] * 4 + [c_long] * 4 + [c_int, c_int, _vp]
+        L.pda_linear_dgrad.argtypes = [_vp] * 4 + [c_int] * 3 + [c_long] * 4 + [c_int, _vp]
+        L.pda_linear_wgrad.argtypes = [_vp] * 4 + [c_int] * 3 + [c_long] * 3 + [c_int, c_int, c_float, c_int, _vp]
+        L.pda_conv_wgrad.argtypes = [_vp] * 4 + [c_int] * 9 + [_vp]
+        L.pda_conv_wgrad_u8.argtypes = [_vp] * 5 + [c_int] * 8 + [c_float, c_int, _vp]
+        L.pda_col2im.argtypes = [_vp] * 3 + [c_int] * 8 + [_vp]
+        L.pda_tr_probe.argtypes = [_vp, _vp]
+        for name in ("pda_conv_fwd_u8", "pda_conv_fwd", "pda_linear_fwd", "pda_linear_dgrad", "pda_linear_wgrad",
+                     "pda_conv_wgrad", "pda_conv_wgrad_u8", "pda_col2im", "pda_tr_probe"):
+            getattr(L, name).restype = None
+        _configured = True
+    return L
+
+
+def conv_out(h, k, s):
+    return (h - k) // s + 1
+
+
+def conv_fwd_u8(frames, idx, w, bias, out, batch, H, W, C, KH, KW, S, O, scale, act=ACT_RELU):
+    """Lists (one entry per problem group, <= 3).  frames: uint8 [*, C, H, W]; idx: int32 [batch] or None."""
+    assert KW == 8 and len(frames) <= 3
+    _L().pda_conv_fwd_u8(_arr(frames), _arr(idx), _arr(w), _arr(bias), _arr(out), len(frames), batch,
+                         H, W, C, KH, KW, S, O, float(scale), act, _stream())
+
+
+def conv_fwd(x, w, bias, out, batch, H, W, C, KH, KW, S, O, act=ACT_RELU):
+    assert C % 8 == 0 and len(x) <= 3
+    _L().pda_conv_fwd(_arr(x), _arr(w), _arr(bias), _arr(out), len(x), batch, H, W, C, KH, KW, S, O, act, _stream())
+
+
+def linear_fwd(x, w, bias, out, out32, M, N, K, ldx, ldw, ldo=0, ldo32=0, act=ACT_NONE, ksplit=0):
+    assert K % 8 == 0 and ldx % 8 == 0 and ldw % 8 == 0 and len(x) <= 3
+    n = len(x)
+    _L().pda_linear_fwd(_arr(x), _arr(w), _arr(bias if bias else [None] * n), _arr(out if out else [None] * n),
+                        _arr(out32 if out32 else [None] * n), n, M, N, K, ldx, ldw, ldo, ldo32, act, ksplit,
+                        _stream())
+
+
+def linear_dgrad(dy, w, y, dx, M, Nout, Kin, lddy, ldw, ldy, lddx, act=ACT_NONE):
+    """dx[M][Kin] = (dy[M][Nout] @ w[Nout][Kin]) * act'(y[M][Kin]) (y None: no mask)."""
+    assert Nout % 8 == 0 and Kin % 8 == 0 and lddy % 8 == 0 and ldw % 8 == 0
+    _L().pda_linear_dgrad(_ptr(dy), _ptr(w), _ptr(y), _ptr(dx), M, Nout, Kin, lddy, ldw, ldy, lddx, act, _stream())
+
+
+def linear_wgrad(dy, x, gw, gb, B, Nout, Kin, lddy, ldx, ldg, C=1, P=None, scale=1.0, ksplit=0):
+    """gw[Nout][perm(Kin)] += dy[B][Nout]^T @ x[B][Kin]; gb[Nout] += column sums of dy.
+    Column k = p*C + c of x lands at gw column c*P + p (C=1: identity)."""
+    assert lddy % 8 == 0 and ldx % 8 == 0
+    _L().pda_linear_wgrad(_ptr(dy), _ptr(x), _ptr(gw), _ptr(gb), B, Nout, Kin, lddy, ldx, ldg, C,
+                          Kin if P is None else P, float(scale), ksplit, _stream())
+
+
+def conv_wgrad(dy, x, gw, gb, batch, H, W, C, KH, KW, S, O, ksplit=0):
+    _L().pda_conv_wgrad(_ptr(dy), _ptr(x), _ptr(gw), _ptr(gb), batch, H, W, C, KH, KW, S, O, ksplit, _stream())
+
+
+def conv_wgrad_u8(dy, frames, idx, gw, gb, batch, H, W, C, KH, KW, S, O, scale, ksplit=0):
+    _L().pda_conv_wgrad_u8(_ptr(dy), _ptr(frames), _ptr(idx), _ptr(gw), _ptr(gb), batch, H, W, C, KH, KW, S, O,
+                           float(scale), ksplit, _stream())
+
+
+def col2im(dcol, yin, dx, batch, H, W, C, KH, KW, S, act=ACT_RELU):
+    _L().pda_col2im(_ptr(dcol), _ptr(yin), _ptr(dx), batch, H, W, C, KH, KW, S, act, _stream())
+
+
+def tr_probe():
+    out = torch.zeros(64 * 8, dtype=torch.int32, device="cuda")
+    _L().pda_tr_probe(_ptr(out), _stream())
+    return out.cpu().reshape(64, 8)
+
+
+# ---- weight layout helpers (torch ops; used at init and by tests) ---------------------------------
+def pack_conv_weight(w):
+    """fp32 [O, C, KH, KW] -> bf16 [O, KH*KW*C] in (ky, kx, c) order."""
+    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(BF16).contiguous()
+
+
+def pack_fc_after_conv(w, C, P):
+    """fp32 [N, C*P] with columns (c, p) -> bf16 [N, P*C] with columns (p, c)."""
+    N = w.shape[0]
+    return w.detach().reshape(N, C, P).permute(0, 2, 1).reshape(N, P * C).to(BF16).contiguous()
+
+
+def nhwc(x):
+    """[B, C, H, W] -> bf16 [B*H*W, C]."""
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).to(BF16).contiguous()
+
+
+def from_nhwc(x, B, H, W, C):
+    return x.float().reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()

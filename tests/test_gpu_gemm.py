@@ -1,0 +1,169 @@
+"""HIP MFMA GEMM family vs plain PyTorch fp32 references (run on a real MI355X).
+Inputs are rounded to bf16 first so the only difference is accumulation order."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nn():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from pytorch_distributed_amd import ops
+    ops.require_native()
+    from pytorch_distributed_amd.ops import nn as _nn
+    return _nn
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def close(a, b, rtol=2e-2, atol=2e-2):
+    err = (a.float() - b.float()).abs().max().item()
+    ref = b.float().abs().max().item()
+    assert err <= atol + rtol * ref, "max err %g vs ref max %g" % (err, ref)
+
+
+def test_tr_probe_mapping(nn):
+    got = nn.tr_probe()
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        for j in range(8):
+            assert int(got[lane, j]) == (8 * g + j) * 72 + i, (lane, j, got[lane].tolist())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 512, 3136), (64, 320, 32), (37, 200, 320), (4096, 64, 576)])
+def test_linear_fwd(nn, M, N, K):
+    torch.manual_seed(0)
+    x = bf(torch.randn(M, K, device="cuda"))
+    w = bf(torch.randn(N, K, device="cuda") / K ** 0.5)
+    b = torch.randn(N, device="cuda")
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    out32 = torch.zeros(M, N, device="cuda")
+    nn.linear_fwd([x.bfloat16()], [w.bfloat16()], [b], [out], [out32], M, N, K, K, K, N, N, act=nn.ACT_RELU)
+    ref = F.relu(x @ w.t() + b)
+    close(out32, ref, 1e-3, 1e-3)
+    close(out, ref)
+    acc = torch.zeros(M, N, device="cuda")
+    nn.linear_fwd([x.bfloat16()], [w.bfloat16()], None, None, [acc], M, N, K, K, K, 0, N, ksplit=256)
+    close(acc, x @ w.t(), 1e-3, 1e-3)
+
+
+def test_linear_fwd_grouped_tanh(nn):
+    torch.manual_seed(1)
+    M, N, K = 64, 96, 64
+    xs = [bf(torch.randn(M, K, device="cuda")) for _ in range(3)]
+    ws = [bf(torch.randn(N, K, device="cuda") / 8) for _ in range(3)]
+    bs = [torch.randn(N, device="cuda") for _ in range(3)]
+    outs = [torch.zeros(M, N, device="cuda") for _ in range(3)]
+    nn.linear_fwd([x.bfloat16() for x in xs], [w.bfloat16() for w in ws], bs, None, outs, M, N, K, K, K, 0, N,
+                  act=nn.ACT_TANH)
+    for x, w, b, o in zip(xs, ws, bs, outs):
+        close(o, torch.tanh(x @ w.t() + b), 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("batch,use_idx", [(32, True), (5, False)])
+def test_conv1_fwd_u8(nn, batch, use_idx):
+    torch.manual_seed(2)
+    mem = torch.randint(0, 256, (64, 4, 84, 84), dtype=torch.uint8, device="cuda")
+    idx = torch.randint(0, 64, (batch,), dtype=torch.int32, device="cuda") if use_idx else None
+    w = bf(torch.randn(32, 4, 8, 8, device="cuda") / 16)
+    b = torch.randn(32, device="cuda")
+    out = torch.zeros(batch * 400, 32, dtype=torch.bfloat16, device="cuda")
+    nn.conv_fwd_u8([mem], [idx], [w.reshape(32, -1).bfloat16().contiguous()], [b], [out], batch, 84, 84, 4, 8, 8, 4, 32,
+                   1.0 / 255.0)
+    x = (mem[idx.long()] if use_idx else mem[:batch]).float() / 255.0
+    ref = F.relu(F.conv2d(x, w, b, stride=4))
+    close(nn.from_nhwc(out, batch, 20, 20, 32), ref)
+
+
+@pytest.mark.parametrize("geom", [(20, 20, 32, 4, 4, 2, 64), (9, 9, 64, 3, 3, 1, 64)])
+def test_conv_fwd_nhwc(nn, geom):
+    H, W, C, KH, KW, S, O = geom
+    torch.manual_seed(3)
+    batch = 16
+    x = bf(torch.randn(batch, C, H, W, device="cuda"))
+    w = bf(torch.randn(O, C, KH, KW, device="cuda") / (C * KH * KW) ** 0.5)
+    b = torch.randn(O, device="cuda")
+    OH, OW = nn.conv_out(H, KH, S), nn.conv_out(W, KW, S)
+    outs = [torch.zeros(batch * OH * OW, O, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+    nn.conv_fwd([nn.nhwc(x), nn.nhwc(x * 0.5)], [nn.pack_conv_weight(w)] * 2, [b, b], outs, batch, H, W, C, KH, KW, S, O)
+    close(nn.from_nhwc(outs[0], batch, OH, OW, O), F.relu(F.conv2d(x, w, b, stride=S)))
+    close(nn.from_nhwc(outs[1], batch, OH, OW, O), F.relu(F.conv2d(x * 0.5, w, b, stride=S)))
+
+
+def test_linear_dgrad_and_wgrad(nn):
+    torch.manual_seed(4)
+    B, Nout, C, P = 128, 512, 64, 49
+    Kin = C * P
+    dy = bf(torch.randn(B, Nout, device="cuda"))
+    w = bf(torch.randn(Nout, Kin, device="cuda") / Kin ** 0.5)      # kernel layout: columns (p, c)
+    x = bf(torch.randn(B, Kin, device="cuda"))
+    y = bf(torch.randn(B, Kin, device="cuda"))
+    dx = torch.zeros(B, Kin, dtype=torch.bfloat16, device="cuda")
+    nn.linear_dgrad(dy.bfloat16(), w.bfloat16(), y.bfloat16(), dx, B, Nout, Kin, Nout, Kin, Kin, Kin, act=nn.ACT_RELU)
+    close(dx, (dy @ w) * (y > 0))
+    nn.linear_dgrad(dy.bfloat16(), w.bfloat16(), y.bfloat16(), dx, B, Nout, Kin, Nout, Kin, Kin, Kin, act=nn.ACT_TANH)
+    close(dx, (dy @ w) * (1 - y * y))
+    gw = torch.zeros(Nout, Kin, device="cuda")
+    gb = torch.zeros(Nout, device="cuda")
+    nn.linear_wgrad(dy.bfloat16(), x.bfloat16(), gw, gb, B, Nout, Kin, Nout, Kin, Kin, C=C, P=P)
+    ref = (dy.t() @ x).reshape(Nout, P, C).permute(0, 2, 1).reshape(Nout, Kin)   # (p,c) -> PyTorch (c,p)
+    close(gw, ref, 1e-3, 1e-3)
+    close(gb, dy.sum(0), 1e-3, 1e-3)
+    # small-M instance (fc2: 6 actions padded to 16 columns), split-K over the batch
+    dq = torch.zeros(B, 16, device="cuda")
+    dq[:, :6] = bf(torch.randn(B, 6, device="cuda"))
+    h = bf(torch.randn(B, 512, device="cuda"))
+    gw2 = torch.zeros(6, 512, device="cuda")
+    gb2 = torch.zeros(6, device="cuda")
+    nn.linear_wgrad(dq.bfloat16(), h.bfloat16(), gw2, gb2, B, 6, 512, 16, 512, 512, ksplit=64)
+    close(gw2, dq[:, :6].t() @ h, 1e-3, 1e-3)
+    close(gb2, dq[:, :6].sum(0), 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("geom", [(20, 20, 32, 4, 4, 2, 64), (9, 9, 64, 3, 3, 1, 64)])
+def test_conv_backward_nhwc(nn, geom):
+    H, W, C, KH, KW, S, O = geom
+    torch.manual_seed(5)
+    batch = 16
+    OH, OW = nn.conv_out(H, KH, S), nn.conv_out(W, KW, S)
+    x = bf(torch.relu(torch.randn(batch, C, H, W, device="cuda"))).requires_grad_(True)
+    w = bf(torch.randn(O, C, KH, KW, device="cuda") / (C * KH * KW) ** 0.5).requires_grad_(True)
+    b = torch.zeros(O, device="cuda", requires_grad=True)
+    dy = bf(torch.randn(batch, O, OH, OW, device="cuda"))
+    F.conv2d(x, w, b, stride=S).backward(dy)
+    # weight / bias gradient
+    gw = torch.zeros(O, C, KH, KW, device="cuda")
+    gb = torch.zeros(O, device="cuda")
+    nn.conv_wgrad(nn.nhwc(dy), nn.nhwc(x.detach()), gw, gb, batch, H, W, C, KH, KW, S, O, ksplit=256)
+    close(gw, w.grad, 2e-3, 2e-3)
+    close(gb, b.grad, 2e-3, 2e-3)
+    # data gradient = dcol GEMM + col2im (masked by relu of the layer input)
+    K = C * KH * KW
+    M = batch * OH * OW
+    dcol = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+    nn.linear_dgrad(nn.nhwc(dy), nn.pack_conv_weight(w), None, dcol, M, O, K, O, K, 0, K)
+    dx = torch.zeros(batch * H * W, C, dtype=torch.bfloat16, device="cuda")
+    nn.col2im(dcol, nn.nhwc(x.detach()), dx, batch, H, W, C, KH, KW, S, act=nn.ACT_RELU)
+    close(nn.from_nhwc(dx, batch, H, W, C), x.grad * (x.detach() > 0), 3e-2, 3e-2)
+
+
+def test_conv1_wgrad_u8(nn):
+    torch.manual_seed(6)
+    batch = 8
+    mem = torch.randint(0, 256, (32, 4, 84, 84), dtype=torch.uint8, device="cuda")
+    idx = torch.randint(0, 32, (batch,), dtype=torch.int32, device="cuda")
+    x = mem[idx.long()].float() / 255.0
+    w = torch.zeros(32, 4, 8, 8, device="cuda", requires_grad=True)
+    b = torch.zeros(32, device="cuda", requires_grad=True)
+    dy = bf(torch.randn(batch, 32, 20, 20, device="cuda"))
+    F.conv2d(x, w, b, stride=4).backward(dy)
+    gw = torch.zeros(32, 256, device="cuda")
+    gb = torch.zeros(32, device="cuda")
+    nn.conv_wgrad_u8(nn.nhwc(dy), mem, idx, gw, gb, batch, 84, 84, 4, 8, 8, 4, 32, 1.0 / 255.0, ksplit=512)
+    close(gw.reshape(32, 4, 8, 8), w.grad, 2e-3, 2e-3)
+    close(gb, b.grad, 2e-3, 2e-3)
