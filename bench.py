@@ -1,0 +1,163 @@
+"""Headline benchmark: Distributed-DQN learner throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Config (BASELINE.json config 2, the reference's README Pong setting): Nature-CNN
+DQN, 6 actions, batch 128 per learner GPU, n-step 5, Adam lr 1e-4, hard target
+update every 250 steps, uniform replay of 50 000 transitions resident in HBM as
+uint8, synthetic Atari-shaped observations (4x84x84 uint8), random-init weights.
+One learner process per GPU; N > 1 = synchronous data parallel (weak scaling:
+128 transitions per GPU per step, RCCL all-reduce of the flat gradient).
+
+Every timed step is a complete learner update: replay sampling, target + online
+forward, TD target/loss, full backward, (all-reduce,) Adam, target update.
+Rank 0 prints ONE JSON line.  `value` = learner updates/s summed over GPUs (one
+update = one batch of 128 transitions through one optimizer step on one GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# reference-style learner loop (host shm replay -> fp32 cast -> H2D -> eager fp32 PyTorch),
+# measured on one MI355X with bench/reference_style.py; see BASELINE.md
+BASELINE_FILE = os.path.join(ROOT, "bench", "reference_measured.json")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=128, help="transitions per GPU per step")
+    ap.add_argument("--replay", type=int, default=50000)
+    ap.add_argument("--config", type=int, default=2, help="options.CONFIGS row (2 uniform, 4 Ape-X PER)")
+    ap.add_argument("--compute", default="native", choices=["native", "torch"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--actor-bench", action="store_true", help="also time batched actor inference (untimed extra)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and rank == 0:
+        print("[bench] WORLD_SIZE=%d but --gpus %d: using WORLD_SIZE" % (world, a.gpus), file=sys.stderr)
+    device = torch.device("cuda:%d" % local)
+    torch.cuda.set_device(device)
+
+    from pytorch_distributed_amd.utils.options import Options
+    from pytorch_distributed_amd.launcher import prepare_options
+    from pytorch_distributed_amd.utils.factory import MemoriesDict, ModelsDict
+    from pytorch_distributed_amd.parallel.comm import comm_from_env
+    from pytorch_distributed_amd.agents.learners import make_core
+
+    comm = comm_from_env(device)
+    opt = prepare_options(Options(config=a.config, overrides={
+        "device": "cuda", "compute": a.compute, "num_learners": world,
+        "memory_params.memory_size": a.replay * world,      # each rank keeps a `replay`-sized shard
+        "agent_params.batch_size": a.batch}))
+    ap_ = opt.agent_params
+    torch.manual_seed(opt.seed)
+
+    def build():
+        return ModelsDict[opt.model_type](opt.model_params, opt.norm_val, opt.state_shape,
+                                          opt.action_space, opt.action_shape).to(device)
+    model, target = build(), build()
+    if world > 1:
+        comm.broadcast_(model.flatten_(), src=0)
+
+    memory = MemoriesDict[opt.memory_type](opt.memory_params)
+    memory.attach(device, rank=rank, world_size=world)
+    gen = torch.Generator(device=device).manual_seed(1000 + rank)
+    gamma_n = ap_.gamma ** ap_.nstep
+    filled = 0
+    while filled < memory.memory_size:      # synthetic transitions, written straight into HBM
+        n = min(4096, memory.memory_size - filled)
+        s = torch.randint(0, 256, (n + 1,) + tuple(opt.state_shape), dtype=torch.uint8, device=device, generator=gen)
+        memory.feed_batch(s[:-1], torch.randint(0, opt.action_space, (n, 1), device=device, generator=gen),
+                          torch.randn(n, 1, device=device, generator=gen).clamp_(-1, 1),
+                          torch.full((n, 1), gamma_n, device=device), s[1:],
+                          (torch.rand(n, 1, device=device, generator=gen) < 0.01).float(),
+                          priorities=torch.rand(n, device=device, generator=gen) + 0.05)
+        filled += n
+    del s
+
+    core = make_core("dqn", opt, model, target, memory, comm, device)
+    if a.no_graph and hasattr(core, "program"):
+        core.program.use_graph = False
+    native = type(core).__name__ == "DqnNativeCore"
+    if a.compute == "native" and not native:
+        raise RuntimeError("native compute requested but the HIP engine is not in use")
+
+    for _ in range(a.warmup):
+        core.step()
+    torch.cuda.synchronize()
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        core.step()
+    torch.cuda.synchronize()
+    comm.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = core.loss_values().get("critic_loss", float("nan"))
+
+    extra = {}
+    if a.actor_bench and rank == 0 and native:
+        from pytorch_distributed_amd.ops.dqn_engine import DqnCnnInference
+        for nact in (8, 256):
+            inf = DqnCnnInference(model, max_batch=nact)
+            obs = torch.randint(0, 256, (nact,) + tuple(opt.state_shape), dtype=torch.uint8, device=device)
+            eps = torch.full((nact,), 0.1, device=device)
+            for _ in range(20):
+                inf.act(obs, eps)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(200):
+                inf.act(obs, eps)[0].cpu()      # actions return to the host every env step
+            dt = time.perf_counter() - t1
+            extra["actor_inference_frames_per_sec_%d_envs" % nact] = round(200 * nact * 4 / dt, 1)  # 4 frames / step
+
+    if rank == 0:
+        ups = world * a.steps / elapsed
+        base = None
+        if os.path.exists(BASELINE_FILE):
+            with open(BASELINE_FILE) as f:
+                base = json.load(f).get("learner_updates_per_sec")
+        out = {
+            "metric": "learner updates/sec (Distributed DQN, Nature-CNN, batch 128 per GPU; summed over GPUs)",
+            "value": round(ups, 2), "unit": "updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": round(ups / base, 2) if base else None,
+            "baseline_note": "reference publishes no throughput; baseline = reference-style learner loop "
+                             "(host shm replay, fp32 eager PyTorch) measured on one MI355X, bench/reference_style.py",
+            "dtype": "bf16" if native else "fp32", "data": "synthetic",
+            "samples_per_sec": round(ups * a.batch, 1), "final_loss": round(float(loss), 6),
+            "config": {"model": "dqn-cnn (Nature CNN, 6 actions, 1,687,206 params)", "global_batch": a.batch * world,
+                       "seq_len": None, "obs": "4x84x84 uint8", "nstep": ap_.nstep, "replay": a.replay,
+                       "replay_kind": "prioritized (HIP sum/min tree)" if memory.enable_per else "uniform",
+                       "optimizer": "adam lr=%g" % ap_.lr, "target_update": ap_.target_model_update,
+                       "parallelism": "dp%d" % world, "engine": type(core).__name__,
+                       "hip_graph": bool(native and not a.no_graph)},
+        }
+        out.update(extra)
+        print(json.dumps(out), flush=True)
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

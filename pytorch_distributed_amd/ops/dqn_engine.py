@@ -1,0 +1,507 @@
+"""Nature-CNN DQN on hand-written gfx950 kernels: learner step and batched actor
+inference (kernels K1-K4, K10, K12-K15 of SURVEY.md section 2.3).
+
+The reference learner step (core/single_processes/dqn_learner.py:50-101) is
+~40 stock PyTorch launches behind a lock-held CPU gather, a uint8->fp32 cast on
+the host and a 28.9 MB unpinned H2D copy.  Here one step is a fixed sequence of
+~20 HIP kernels on data that never leaves HBM, captured once into a hipGraph:
+
+  sample      uniform counter-hash draw, or radix-64 sum-tree descent (PER)
+  forward     conv1 reads uint8 replay frames *through the index vector* (no
+              gather copy, /255 folded into the epilogue); online(s0), target(sN)
+              and -- for double DQN -- online(sN) run as problem groups of the
+              SAME launches; activations bf16 NHWC; fc1 split-K into fp32
+  head        fc2 + n-step TD target + (importance-weighted) MSE + dL/dq + fc2
+              dgrad + relu mask + PER leaf priorities, one wave64 per sample
+  backward    MFMA wgrad/dgrad GEMMs, fp32 atomics straight into the flat
+              gradient buffer in PyTorch's parameter layout
+  (DP)        RCCL all-reduce of the flat gradient: the fc tail (95 % of the
+              bytes) is reduced on a side stream while the conv backward runs
+  update      one fused clip+Adam launch that also re-emits the bf16 shadow
+              weights; fused hard/soft target update; sum/min-tree repair
+
+fp32 master weights live in the model's own flat buffer, so state_dict(),
+checkpoints and weight publishing see ordinary PyTorch parameters.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib, nn
+from .optim import FlatAdam, SegmentTable, polyak_
+
+_vp = ctypes.c_void_p
+BF16 = torch.bfloat16
+HID_SUPPORTED = (256, 512)
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else 0
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+class _HeadArgs(ctypes.Structure):     # mirrors DqnHeadArgs in csrc/rl_kernels.hip
+    _fields_ = [("h1pre_on0", _vp), ("h1pre_tg1", _vp), ("h1pre_on1", _vp),
+                ("b4_on", _vp), ("b4_tg", _vp),
+                ("w5_on", _vp), ("b5_on", _vp), ("w5_tg", _vp), ("b5_tg", _vp),
+                ("tails", _vp), ("tail_ld", ctypes.c_int), ("off_action", ctypes.c_int),
+                ("off_reward", ctypes.c_int), ("off_gamma", ctypes.c_int), ("off_term", ctypes.c_int),
+                ("idx", _vp), ("isw", _vp),
+                ("h1_on0", _vp), ("dh1", _vp), ("dq", _vp), ("dq_ld", ctypes.c_int),
+                ("q_out", _vp), ("td_out", _vp), ("loss_sum", _vp),
+                ("leaf_sum", _vp), ("leaf_min", _vp), ("prio_eps", ctypes.c_float), ("prio_alpha", ctypes.c_float),
+                ("B", ctypes.c_int), ("HID", ctypes.c_int), ("A", ctypes.c_int)]
+
+
+class _ActArgs(ctypes.Structure):      # mirrors ActHeadArgs
+    _fields_ = [("h1pre", _vp), ("b4", _vp), ("w5", _vp), ("b5", _vp),
+                ("eps", _vp), ("out", _vp), ("out_ld", ctypes.c_int),
+                ("q_out", _vp), ("B", ctypes.c_int), ("HID", ctypes.c_int), ("A", ctypes.c_int),
+                ("seed", ctypes.c_ulonglong), ("counter", _vp)]
+
+
+_lib_ready = False
+
+
+def _L():
+    global _lib_ready
+    L = lib()
+    if not _lib_ready:
+        L.pda_dqn_head.argtypes = [ctypes.POINTER(_HeadArgs), _vp]
+        L.pda_dqn_head.restype = None
+        L.pda_act_head.argtypes = [ctypes.POINTER(_ActArgs), _vp]
+        L.pda_act_head.restype = None
+        L.pda_uniform_idx.argtypes = [_vp, _vp, ctypes.c_int, _vp, ctypes.c_ulonglong, _vp, _vp]
+        L.pda_uniform_idx.restype = None
+        L.pda_uniform_f32.argtypes = [_vp, ctypes.c_int, ctypes.c_ulonglong, _vp, _vp]
+        L.pda_uniform_f32.restype = None
+        _lib_ready = True
+    return L
+
+
+def _ksplit(red, tiles, target_blocks=768, minimum=64):
+    """Split-K slice length (multiple of 32) so that tiles * slices ~ target_blocks."""
+    slices = max(1, target_blocks // max(tiles, 1))
+    ks = (red + slices - 1) // slices
+    ks = max(minimum, (ks + 31) // 32 * 32)
+    return ks
+
+
+class CnnGeometry(object):
+    def __init__(self, input_dims, num_actions, hidden=512):
+        C, H, W = input_dims
+        self.C, self.H, self.W = C, H, W
+        self.H1, self.W1 = nn.conv_out(H, 8, 4), nn.conv_out(W, 8, 4)
+        self.H2, self.W2 = nn.conv_out(self.H1, 4, 2), nn.conv_out(self.W1, 4, 2)
+        self.H3, self.W3 = nn.conv_out(self.H2, 3, 1), nn.conv_out(self.W2, 3, 1)
+        self.P3 = self.H3 * self.W3
+        self.F = 64 * self.P3
+        self.K1, self.K2, self.K3 = C * 64, 32 * 16, 64 * 9
+        self.A, self.HID = int(num_actions), int(hidden)
+        if W % 4 or (C * H * W) % 4:
+            raise ValueError("uint8 conv1 loader needs 4-byte aligned rows (W %% 4 == 0)")
+        if self.HID not in HID_SUPPORTED or self.A > 64:
+            raise ValueError("unsupported head shape")
+
+
+class CnnWeights(object):
+    """Views of one network's flat fp32 parameters + its bf16 shadow weights in
+    kernel layout (conv: [O][(ky,kx,c)], conv1: [O][(c,ky,kx)], fc1: [N][(p,c)])."""
+
+    ORDER = ("critic.0.0", "critic.0.2", "critic.0.4", "critic.1.0", "critic.1.2")
+
+    def __init__(self, model, geom, with_grad):
+        self.model, self.g = model, geom
+        self.flat = model.flatten_(with_grad=with_grad)
+        dev = self.flat.device
+        segs = {name: (off, shape) for name, off, shape in model.param_segments()}
+        g = geom
+        shadow_shapes = [(32, g.K1, 1, g.K1), (64, g.K2, 32, 16), (64, g.K3, 64, 9), (g.HID, g.F, 64, g.P3)]
+        total = sum(r * c for r, c, _, _ in shadow_shapes)
+        self.shadow = torch.zeros(total, dtype=BF16, device=dev)
+        entries, self.w, self.b, self.off = [], [], [], {}
+        soff = 0
+        for li, layer in enumerate(self.ORDER):
+            woff, wshape = segs[layer + ".weight"]
+            boff, bshape = segs[layer + ".bias"]
+            wn, bn = int(np.prod(wshape)), int(np.prod(bshape))
+            self.off[layer] = (woff, wn, boff, bn)
+            ent = {"start": woff, "count": wn, "cols": wn // wshape[0]}
+            if li < 4:
+                rows, cols, C, P = shadow_shapes[li]
+                assert rows == wshape[0] and cols == wn // wshape[0], (layer, wshape, rows, cols)
+                ent.update(C=C, P=P, shadow_off=soff, shadow_ld=cols, shadow=True)
+                self.w.append(self.shadow[soff:soff + rows * cols].view(rows, cols))
+                soff += rows * cols
+            else:
+                self.w.append(self.flat[woff:woff + wn].view(wshape))       # fc2 stays fp32
+            entries.append(ent)
+            entries.append({"start": boff, "count": bn})
+            self.b.append(self.flat[boff:boff + bn])
+        self.table = SegmentTable(entries, dev)
+        self.refresh()
+
+    def refresh(self):
+        """Rebuild the bf16 shadows from the fp32 master weights (after a load)."""
+        polyak_(self.flat, self.flat, 1.0, self.table, self.shadow)
+
+    def grad_views(self, flat_grads):
+        gw, gb = [], []
+        for layer in self.ORDER:
+            woff, wn, boff, bn = self.off[layer]
+            gw.append(flat_grads[woff:woff + wn])
+            gb.append(flat_grads[boff:boff + bn])
+        return gw, gb
+
+
+class _Acts(object):
+    def __init__(self, geom, B, groups, device, backward):
+        g = geom
+        z = lambda *s, dtype=BF16: torch.zeros(*s, dtype=dtype, device=device)
+        self.a1 = [z(B * g.H1 * g.W1, 32) for _ in range(groups)]
+        self.a2 = [z(B * g.H2 * g.W2, 64) for _ in range(groups)]
+        self.a3 = [z(B * g.P3, 64) for _ in range(groups)]
+        self.h1pre = [z(B, g.HID, dtype=torch.float32) for _ in range(groups)]
+        if backward:
+            self.h1 = z(B, g.HID)
+            self.dh1 = z(B, g.HID)
+            self.dq_ld = max(16, (g.A + 7) // 8 * 8)
+            self.dq = z(B, self.dq_ld)
+            self.da3 = z(B * g.P3, 64)
+            self.dcol3 = z(B * g.P3, g.K3)
+            self.da2 = z(B * g.H2 * g.W2, 64)
+            self.dcol2 = z(B * g.H2 * g.W2, g.K2)
+            self.da1 = z(B * g.H1 * g.W1, 32)
+
+
+def cnn_forward(geom, nets, frames, idxs, acts, B, norm_val):
+    """Run len(nets) (<= 3) networks as problem groups of the same launches.
+    Leaves fc1's pre-activation split-K sums in acts.h1pre[g] (which must be zero)."""
+    g, n = geom, len(nets)
+    nn.conv_fwd_u8(frames, idxs, [w.w[0] for w in nets], [w.b[0] for w in nets], acts.a1[:n], B,
+                   g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / float(norm_val))
+    nn.conv_fwd(acts.a1[:n], [w.w[1] for w in nets], [w.b[1] for w in nets], acts.a2[:n], B, g.H1, g.W1, 32, 4, 4, 2, 64)
+    nn.conv_fwd(acts.a2[:n], [w.w[2] for w in nets], [w.b[2] for w in nets], acts.a3[:n], B, g.H2, g.W2, 64, 3, 3, 1, 64)
+    tiles = ((B + 63) // 64) * (g.HID // 64) * n
+    nn.linear_fwd(acts.a3[:n], [w.w[3] for w in nets], None, None, acts.h1pre[:n], B, g.HID, g.F, g.F, g.F,
+                  0, g.HID, ksplit=_ksplit(g.F, tiles, 768, 128))
+
+
+class DqnCnnEngine(object):
+    """One learner's device state and step program."""
+
+    def __init__(self, model, target_model, batch_size, lr=1e-4, weight_decay=0.0, clip=np.inf,
+                 double=False, target_update=250, per=None, seed=0, tail_offsets=(0, 1, 2, 3)):
+        self.geom = g = CnnGeometry(model.input_dims, model.output_dims, model.critic[1][0].out_features)
+        self.B = int(batch_size)
+        self.norm_val = float(model.norm_val)
+        self.double = bool(double)
+        self.target_update = target_update
+        self.per = per                      # None or dict(eps, alpha, beta)
+        self.online = CnnWeights(model, g, with_grad=True)
+        self.target = CnnWeights(target_model, g, with_grad=False)
+        self.device = dev = self.online.flat.device
+        self.grads = model.flat_grads
+        self.grads.zero_()
+        self.gw, self.gb = self.online.grad_views(self.grads)
+        self.adam = FlatAdam(self.online.flat, self.grads, self.online.table, lr=lr, weight_decay=weight_decay,
+                             clip=clip, shadow=self.online.shadow)
+        self.groups = 3 if self.double else 2
+        self.acts = _Acts(g, self.B, self.groups, dev, backward=True)
+        self.idx = torch.zeros(self.B, dtype=torch.int32, device=dev)
+        self.isw = torch.ones(self.B, dtype=torch.float32, device=dev)
+        self.uniforms = torch.zeros(self.B, dtype=torch.float32, device=dev)
+        self.td = torch.zeros(self.B, dtype=torch.float32, device=dev)
+        self.q = torch.zeros(self.B, g.A, dtype=torch.float32, device=dev)
+        self.loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.loss_steps = 0
+        self.size_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.seed = int(seed) & 0xFFFFFFFFFFFF
+        self.tail_offsets = tuple(int(o) for o in tail_offsets)
+        self.replay = None
+        self.step_count = 0
+        # the tail bucket [fc1.weight .. end] is ready right after the two fc wgrads
+        self.tail_start = self.online.off["critic.1.0"][0]
+        polyak_(self.target.flat, self.online.flat, 1.0, self.target.table, self.target.shadow)   # hard copy to start
+
+    # ---- data sources --------------------------------------------------------------------------
+    def bind_replay(self, state0s, state1s, tails, tree=None):
+        """HBM replay: uint8 [M,C,H,W] x2 and fp32 tails [M][tail_ld] on this device."""
+        assert state0s.dtype == torch.uint8 and state0s.is_cuda and tails.dtype == torch.float32
+        self.replay = (state0s, state1s, tails, tree)
+        return self
+
+    def make_staging(self, tail_floats):
+        """Staging buffers for replay kept on the host (memory_type "shared")."""
+        g, dev = self.geom, self.device
+        self.stage_s0 = torch.zeros(self.B, g.C, g.H, g.W, dtype=torch.uint8, device=dev)
+        self.stage_s1 = torch.zeros_like(self.stage_s0)
+        self.stage_tails = torch.zeros(self.B, tail_floats, dtype=torch.float32, device=dev)
+        return self
+
+    # ---- step pieces (each only enqueues kernels on the current stream) ------------------------------
+    def sample(self):
+        s0, s1, tails, tree = self.replay
+        L = _L()
+        if tree is not None and self.per is not None:
+            L.pda_uniform_f32(_p(self.uniforms), self.B, self.seed, _p(self.counter), _stream())
+            tree.sample(self.uniforms, float(self.per["beta"]), self.idx, self.isw)
+        else:
+            L.pda_uniform_idx(_p(self.idx), _p(self.isw), self.B, _p(self.size_dev), self.seed, _p(self.counter),
+                              _stream())
+
+    def _sources(self, staged):
+        if staged:
+            return self.stage_s0, self.stage_s1, self.stage_tails, None, None
+        s0, s1, tails, tree = self.replay
+        return s0, s1, tails, self.idx, (tree if self.per is not None else None)
+
+    def forward_head(self, staged=False):
+        g, B, a = self.geom, self.B, self.acts
+        s0, s1, tails, idx, tree = self._sources(staged)
+        nets = [self.online, self.target] + ([self.online] if self.double else [])
+        frames = [s0, s1] + ([s1] if self.double else [])
+        cnn_forward(g, nets, frames, [idx] * len(nets), a, B, self.norm_val)
+        on, tg = self.online, self.target
+        oa, orw, og, ot = self.tail_offsets
+        args = _HeadArgs(
+            h1pre_on0=_p(a.h1pre[0]), h1pre_tg1=_p(a.h1pre[1]), h1pre_on1=_p(a.h1pre[2]) if self.double else 0,
+            b4_on=_p(on.b[3]), b4_tg=_p(tg.b[3]),
+            w5_on=_p(on.w[4]), b5_on=_p(on.b[4]), w5_tg=_p(tg.w[4]), b5_tg=_p(tg.b[4]),
+            tails=_p(tails), tail_ld=int(tails.stride(0)), off_action=oa, off_reward=orw, off_gamma=og, off_term=ot,
+            idx=_p(idx), isw=_p(self.isw) if (self.per is not None) else 0,
+            h1_on0=_p(a.h1), dh1=_p(a.dh1), dq=_p(a.dq), dq_ld=a.dq_ld,
+            q_out=_p(self.q), td_out=_p(self.td), loss_sum=_p(self.loss_acc),
+            leaf_sum=_p(tree.sum) if tree is not None else 0, leaf_min=_p(tree.min) if tree is not None else 0,
+            prio_eps=float(self.per["eps"]) if self.per else 0.0,
+            prio_alpha=float(self.per["alpha"]) if self.per else 1.0,
+            B=B, HID=g.HID, A=g.A)
+        _L().pda_dqn_head(ctypes.byref(args), _stream())
+
+    def backward_fc(self):
+        g, B, a = self.geom, self.B, self.acts
+        nn.linear_wgrad(a.dq, a.h1, self.gw[4], self.gb[4], B, g.A, g.HID, a.dq_ld, g.HID, g.HID)
+        nn.linear_wgrad(a.dh1, a.a3[0], self.gw[3], self.gb[3], B, g.HID, g.F, g.HID, g.F, g.F, C=64, P=g.P3)
+
+    def backward_conv(self, staged=False):
+        g, B, a = self.geom, self.B, self.acts
+        s0, _, _, idx, _ = self._sources(staged)
+        on = self.online
+        M3, M2, M1 = B * g.P3, B * g.H2 * g.W2, B * g.H1 * g.W1
+        nn.linear_dgrad(a.dh1, on.w[3], a.a3[0], a.da3, B, g.HID, g.F, g.HID, g.F, g.F, g.F, act=nn.ACT_RELU)
+        nn.conv_wgrad(a.da3, a.a2[0], self.gw[2], self.gb[2], B, g.H2, g.W2, 64, 3, 3, 1, 64,
+                      ksplit=_ksplit(M3, (g.K3 + 63) // 64))
+        nn.linear_dgrad(a.da3, on.w[2], None, a.dcol3, M3, 64, g.K3, 64, g.K3, 0, g.K3)
+        nn.col2im(a.dcol3, a.a2[0], a.da2, B, g.H2, g.W2, 64, 3, 3, 1, act=nn.ACT_RELU)
+        nn.conv_wgrad(a.da2, a.a1[0], self.gw[1], self.gb[1], B, g.H1, g.W1, 32, 4, 4, 2, 64,
+                      ksplit=_ksplit(M2, (g.K2 + 63) // 64))
+        nn.linear_dgrad(a.da2, on.w[1], None, a.dcol2, M2, 64, g.K2, 64, g.K2, 0, g.K2)
+        nn.col2im(a.dcol2, a.a1[0], a.da1, B, g.H1, g.W1, 32, 4, 4, 2, act=nn.ACT_RELU)
+        nn.conv_wgrad_u8(a.da1, s0, idx, self.gw[0], self.gb[0], B, g.H, g.W, g.C, 8, 8, 4, 32,
+                         1.0 / self.norm_val, ksplit=_ksplit(M1, (g.K1 + 63) // 64))
+
+    def update(self, staged=False):
+        self.adam.step()
+        if self.target_update < 1.0:
+            polyak_(self.target.flat, self.online.flat, float(self.target_update), self.target.table,
+                    self.target.shadow)
+        if not staged and self.per is not None and self.replay[3] is not None:
+            self.replay[3].repair(self.idx, self.B)
+
+    def hard_target_update(self):
+        polyak_(self.target.flat, self.online.flat, 1.0, self.target.table, self.target.shadow)
+
+    def set_size(self, n):
+        self.size_dev.fill_(int(n))
+
+    def mean_loss(self):
+        """Mean loss since the last call (one host sync)."""
+        n = max(self.loss_steps, 1)
+        val = float(self.loss_acc.item()) / n
+        self.loss_acc.zero_()
+        self.loss_steps = 0
+        return val
+
+
+class DqnStepProgram(object):
+    """Sequences an engine's step and captures it into hipGraphs.
+
+    world_size == 1: one graph per step.  Data parallel: the step is cut where
+    the collectives go -- [sample, forward, head, fc wgrad] | all-reduce(fc tail)
+    on the comm stream, overlapped with [conv backward] | all-reduce(conv head)
+    | [adam, target, tree repair]."""
+
+    def __init__(self, engine, comm=None, use_graph=True, staged=False):
+        self.e, self.comm, self.staged = engine, comm, staged
+        self.world = comm.world_size if comm is not None else 1
+        self.use_graph = use_graph
+        self.graphs = None
+        self.calls = 0
+        if self.world > 1:
+            self.comm_stream = torch.cuda.Stream(device=engine.device)
+            self.fc_done = torch.cuda.Event()
+            self.tail = engine.grads[engine.tail_start:]
+            self.head = engine.grads[:engine.tail_start]
+
+    def _part_a(self):
+        if not self.staged:
+            self.e.sample()
+        self.e.forward_head(self.staged)
+        self.e.backward_fc()
+
+    def _part_b(self):
+        self.e.backward_conv(self.staged)
+
+    def _part_c(self):
+        self.e.update(self.staged)
+
+    def _capture(self, fns):
+        graphs = []
+        for fn in fns:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                fn()
+            graphs.append(gr)
+        return graphs
+
+    def _run_parts(self, parts):
+        if self.world == 1:
+            for p in parts:
+                p()
+            return
+        a, b, c = parts
+        cur = torch.cuda.current_stream()
+        a()
+        self.fc_done.record(cur)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(self.fc_done)
+            self.comm.all_reduce_mean_(self.tail)
+        b()
+        self.comm.all_reduce_mean_(self.head)
+        cur.wait_stream(self.comm_stream)
+        c()
+
+    def step(self):
+        e = self.e
+        eager = [self._part_a, self._part_b, self._part_c]
+        if not self.use_graph or self.calls == 0:
+            # the first step runs eagerly: it loads every code object, so nothing is
+            # lazily initialised while a stream is capturing
+            self._run_parts(eager)
+        else:
+            if self.graphs is None:
+                if self.world == 1:
+                    self.graphs = self._capture([lambda: (self._part_a(), self._part_b(), self._part_c())])
+                else:
+                    self.graphs = self._capture(eager)
+            if self.world == 1:
+                self.graphs[0].replay()
+            else:
+                self._run_parts([g.replay for g in self.graphs])
+        self.calls += 1
+        e.loss_steps += 1
+        if e.target_update >= 1.0 and e.step_count % int(e.target_update) == 0:
+            e.hard_target_update()
+        e.step_count += 1
+
+
+class DqnNativeCore(object):
+    """Learner-loop adapter (agents/learners.py): same surface as DqnTorchCore."""
+
+    def __init__(self, args, model, target_model, memory, comm=None, use_graph=True):
+        ap, mp_ = args.agent_params, args.memory_params
+        self.args, self.ap, self.memory, self.comm = args, ap, memory, comm
+        self.model, self.target_model = model, target_model
+        per = None
+        if memory.enable_per:
+            per = {"eps": memory.priority_eps, "alpha": memory.priority_exponent, "beta": memory.priority_weight}
+        a, k = int(memory.action_shape), int(memory.reward_shape)
+        rank = comm.rank if comm is not None else 0
+        self.engine = DqnCnnEngine(model, target_model, ap.batch_size, lr=ap.lr, weight_decay=ap.weight_decay,
+                                   clip=ap.clip_grad, double=ap.enable_double,
+                                   target_update=ap.target_model_update, per=per,
+                                   seed=args.seed * 7919 + 104729 * rank + 13, tail_offsets=(0, a, a + k, a + 2 * k))
+        self.on_device = hasattr(memory, "tails") and getattr(memory, "attached", False) and memory.tails.is_cuda
+        if self.on_device:
+            self.engine.bind_replay(memory.state0s, memory.state1s, memory.tails, memory.tree)
+        else:
+            self.engine.make_staging(a + 3 * k + 1)
+        self.program = DqnStepProgram(self.engine, comm, use_graph=use_graph, staged=not self.on_device)
+        self._last_size = -1
+        self.step_count = 0
+
+    def step(self):
+        e = self.engine
+        if self.on_device:
+            n = self.memory.size
+            if n != self._last_size:
+                e.set_size(n)
+                self._last_size = n
+            self.program.step()
+        else:
+            batch, inds, weights = self.memory.sample_with_priorities(self.ap.batch_size)
+            s0, a, r, g, s1, t = batch
+            e.stage_s0.copy_(s0.to(torch.uint8), non_blocking=True)
+            e.stage_s1.copy_(s1.to(torch.uint8), non_blocking=True)
+            tails = torch.cat([a.float().reshape(e.B, -1), r.float().reshape(e.B, -1), g.float().reshape(e.B, -1),
+                               t.float().reshape(e.B, -1)], dim=1)
+            e.stage_tails[:, :tails.shape[1]].copy_(tails, non_blocking=True)
+            e.isw.copy_(weights.reshape(-1).float(), non_blocking=True)
+            self.program.step()
+            if self.memory.enable_per and inds is not None:
+                self.memory.update_priorities(inds, e.td.abs().cpu())
+        self.step_count += 1
+
+    def flat_params(self):
+        return self.engine.online.flat
+
+    def loss_values(self):
+        return {"critic_loss": self.engine.mean_loss()}
+
+
+class DqnCnnInference(object):
+    """Batched actor-side forward + epsilon-greedy epilogue (kernel K10)."""
+
+    def __init__(self, model, max_batch, seed=0):
+        self.geom = g = CnnGeometry(model.input_dims, model.output_dims, model.critic[1][0].out_features)
+        self.model = model
+        self.norm_val = float(model.norm_val)
+        self.weights = CnnWeights(model, g, with_grad=False)
+        self.device = dev = self.weights.flat.device
+        self.max_batch = int(max_batch)
+        self.acts = _Acts(g, self.max_batch, 1, dev, backward=False)
+        self.out = torch.zeros(self.max_batch, 4, dtype=torch.float32, device=dev)
+        self.q = torch.zeros(self.max_batch, g.A, dtype=torch.float32, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.seed = (int(seed) * 2654435761 + 97) & 0xFFFFFFFFFFFF
+
+    def refresh_weights(self):
+        if self.weights.flat.data_ptr() != self.model.flat_params.data_ptr():
+            self.weights = CnnWeights(self.model, self.geom, with_grad=False)
+        else:
+            self.weights.refresh()
+
+    @torch.no_grad()
+    def act(self, obs, eps=None):
+        """obs uint8 (n,C,H,W) on the device; eps fp32 (n,) or None (greedy).
+        Returns device tensors (action int64 (n,), q[action] (n,), max q (n,))."""
+        n = int(obs.shape[0])
+        assert n <= self.max_batch and obs.dtype == torch.uint8 and obs.is_contiguous()
+        g = self.geom
+        cnn_forward(g, [self.weights], [obs], [None], self.acts, n, self.norm_val)
+        w = self.weights
+        args = _ActArgs(h1pre=_p(self.acts.h1pre[0]), b4=_p(w.b[3]), w5=_p(w.w[4]), b5=_p(w.b[4]),
+                        eps=_p(eps) if eps is not None else 0, out=_p(self.out), out_ld=4, q_out=_p(self.q),
+                        B=n, HID=g.HID, A=g.A, seed=self.seed, counter=_p(self.counter))
+        _L().pda_act_head(ctypes.byref(args), _stream())
+        self.counter += 1
+        out = self.out[:n]
+        return out[:, 0].long(), out[:, 1].clone(), out[:, 2].clone()
+
+    def q_values(self, n):
+        return self.q[:n]

@@ -1,0 +1,115 @@
+"""Flat-buffer optimizer / target-update kernels (K13-K15): python bindings.
+
+`FlatAdam` drives csrc/rl_kernels.hip:adam_kernel: ONE launch clips the gradient
+by value, applies Adam to every parameter of a model's flat fp32 buffer, zeroes
+the gradient for the next accumulation and re-emits the bf16 "shadow" weights in
+the layouts the MFMA kernels read.  Hyper-parameters and the step counter live
+in device memory so the launch can sit inside a captured hipGraph.
+`polyak_` is the fused hard/soft target update (reference utils/helpers.py:19-25
+loops over parameters in Python).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib
+
+OPT_CHUNK = 2048
+_vp = ctypes.c_void_p
+
+
+def _p(t):
+    return _vp(t.data_ptr()) if t is not None else _vp(0)
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+class SegmentTable(object):
+    """Device tables describing each parameter tensor of a flat buffer.
+    entries: dicts with start, count, cols, C, P, shadow_off, shadow_ld, shadow(bool)."""
+
+    def __init__(self, entries, device):
+        rows, chunks = [], []
+        for si, e in enumerate(entries):
+            rows.append([e["start"], e["count"], e.get("cols", e["count"]), e.get("C", 1),
+                         e.get("P", e.get("cols", e["count"])), e.get("shadow_off", 0), e.get("shadow_ld", 0),
+                         1 if e.get("shadow", False) else 0])
+            for first in range(0, e["count"], OPT_CHUNK):
+                chunks.append([si, first])
+        self.segs = torch.tensor(rows, dtype=torch.int32).to(device)
+        self.chunks = torch.tensor(chunks, dtype=torch.int32).to(device)
+        self.nchunks = len(chunks)
+
+
+def plain_table(numel, device):
+    return SegmentTable([{"start": 0, "count": int(numel)}], device)
+
+
+class FlatAdam(object):
+    def __init__(self, flat_params, flat_grads, table, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 clip=np.inf, grad_scale=1.0, shadow=None):
+        dev = flat_params.device
+        self.p, self.g, self.table, self.shadow = flat_params, flat_grads, table, shadow
+        self.m = torch.zeros_like(flat_params)
+        self.v = torch.zeros_like(flat_params)
+        clip = float(clip) if np.isfinite(clip) else 3.0e38
+        self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, clip, grad_scale],
+                                  dtype=torch.float32).to(dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        L = lib()
+        L.pda_adam.argtypes = [_vp] * 7 + [ctypes.c_int, _vp, _vp, _vp]
+        L.pda_adam.restype = None
+
+    def set_lr(self, lr):
+        self.hyper[0] = float(lr)
+
+    def step(self):
+        lib().pda_adam(_p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.shadow), _p(self.table.segs),
+                       _p(self.table.chunks), self.table.nchunks, _p(self.hyper), _p(self.step_dev), _stream())
+
+
+def polyak_(tgt_flat, src_flat, tau, table=None, shadow=None):
+    """tgt = (1-tau) tgt + tau src over flat fp32 buffers; tau >= 1 is a hard copy.
+    With a table + shadow the target's bf16 shadow weights are re-emitted too."""
+    L = lib()
+    if table is None:
+        L.pda_polyak_flat.argtypes = [_vp, _vp, ctypes.c_long, ctypes.c_float, _vp]
+        L.pda_polyak_flat.restype = None
+        if tau >= 1.0:
+            tgt_flat.copy_(src_flat)
+        else:
+            L.pda_polyak_flat(_p(tgt_flat), _p(src_flat), int(tgt_flat.numel()), float(tau), _stream())
+        return
+    L.pda_polyak.argtypes = [_vp] * 5 + [ctypes.c_int, ctypes.c_float, _vp]
+    L.pda_polyak.restype = None
+    L.pda_polyak(_p(tgt_flat), _p(src_flat), _p(shadow), _p(table.segs), _p(table.chunks), table.nchunks,
+                 float(tau), _stream())
+
+
+def polyak_params_(dst_params, src_params, tau):
+    """Soft update of parameter lists living on a GPU.  Returns False when the
+    native library is unavailable (caller falls back to torch._foreach)."""
+    from . import native_available
+    if not native_available():
+        return False
+    for d, s in zip(dst_params, src_params):
+        if not (d.is_contiguous() and s.is_contiguous() and d.dtype == torch.float32 and s.dtype == torch.float32):
+            return False
+    # parameters of a flattened model are adjacent views: merge them into runs so a
+    # whole model is one launch
+    runs = []
+    for d, s in zip(dst_params, src_params):
+        dp, sp, n = d.data_ptr(), s.data_ptr(), d.numel()
+        if runs and runs[-1][0] + 4 * runs[-1][2] == dp and runs[-1][1] + 4 * runs[-1][2] == sp:
+            runs[-1][2] += n
+        else:
+            runs.append([dp, sp, n])
+    L = lib()
+    L.pda_polyak_flat.argtypes = [_vp, _vp, ctypes.c_long, ctypes.c_float, _vp]
+    L.pda_polyak_flat.restype = None
+    for dp, sp, n in runs:
+        L.pda_polyak_flat(_vp(dp), _vp(sp), n, float(tau), _stream())
+    return True

@@ -112,7 +112,10 @@ class TorchComm(SingleComm):
         return bool(self._flag.item())
 
     def barrier(self):
-        dist.barrier()
+        if self.device.type == "cuda":
+            dist.barrier(device_ids=[self.device.index if self.device.index is not None else 0])
+        else:
+            dist.barrier()
 
     def close(self):
         if self.owns_group and dist.is_initialized():
