@@ -204,21 +204,23 @@ struct EpiMaskBf16 {    // dgrad: out = acc * act'(y[m][n]) -> bf16 ; y is the f
     __device__ __forceinline__ void bias_grad(int, float, int) const {}
 };
 
-// weight gradient: atomicAdd into the flat fp32 gradient buffer in PyTorch layout.
-// GEMM col n = p*C + c (kernel layout)  ->  destination col c*P + p.
+// weight gradient: plain stores of this block's split-K partial tile into slab slice
+// blockIdx.y, in GEMM (kernel) layout [m][n].  A single-slice launch writes the gradient
+// buffer itself; multi-slice launches write a scratch slab that wgrad_reduce_kernel sums.
+// (fp32 atomics execute memory-side on MI355X and the PyTorch-layout scatter made every
+// lane its own 64-B request: 134 us per conv wgrad in the first profile.)
 struct EpiWgrad {
-    float* gw; float* gb; int C; int P; long ld; float scale;
+    float* gw; float* gb; long ld; long slice_stride; long bslice_stride; float scale;
     static constexpr bool kBiasGrad = true;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N) const {
         if (n >= N) return;
-        int p = n / C, c = n - p * C;
-        long col = (long)c * P + p;
+        float* dst = gw + (long)blockIdx.y * slice_stride;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (m + r < M) atomicAdd(&gw[(long)(m + r) * ld + col], v[r] * scale);
+            if (m + r < M) dst[(long)(m + r) * ld + n] = v[r] * scale;
     }
     __device__ __forceinline__ void bias_grad(int m, float v, int M) const {
-        if (gb && m < M) atomicAdd(&gb[m], v);
+        if (gb && m < M) gb[(long)blockIdx.y * bslice_stride + m] = v;
     }
 };
 

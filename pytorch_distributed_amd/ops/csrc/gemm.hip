@@ -94,46 +94,88 @@ PDA_EXPORT void pda_linear_dgrad(const void* dy, const void* w, const void* y, v
     else launch_gemm<64, 64, 2, 2>(a, 1, M, Kin, Nout, 0, stream);
 }
 
-// ---- weight gradient of a linear map: gw[Nout][perm(Kin)] += dy^T[Nout][B] * x[B][Kin] --------
+// ---- weight gradients -----------------------------------------------------------------------------
+// All three write split-K partial tiles with plain stores in GEMM layout: slice y goes to
+// gw + y*slice_stride (+ bias column sums to gb + y*bslice_stride).  With one slice gw/gb can be
+// the gradient buffer itself; otherwise they are scratch slabs summed by pda_wgrad_reduce.
+// linear: gw[Nout][Kin] = dy[B][Nout]^T x[B][Kin]
 PDA_EXPORT void pda_linear_wgrad(const void* dy, const void* x, void* gw, void* gb, int B, int Nout, int Kin,
-                                 long lddy, long ldx, long ldg, int C, int P, float scale, int ksplit,
-                                 hipStream_t stream) {
+                                 long lddy, long ldx, long ldg, long slice_stride, long bslice_stride, float scale,
+                                 int ksplit, hipStream_t stream) {
     GemmArgs<SrcDenseT, SrcDenseT, EpiWgrad> a;
     a.g[0].a = {(const bf16_t*)dy, lddy, Nout, B};
     a.g[0].b = {(const bf16_t*)x, ldx, Kin, B};
-    a.g[0].e = {(float*)gw, (float*)gb, C, P, ldg, scale};
+    a.g[0].e = {(float*)gw, (float*)gb, ldg, slice_stride, bslice_stride, scale};
     a.g[0].M = Nout; a.g[0].N = Kin; a.g[0].K = B;
     if (Nout <= 32) launch_gemm<32, 64, 1, 4>(a, 1, Nout, Kin, B, ksplit, stream);
     else launch_gemm<64, 64, 2, 2>(a, 1, Nout, Kin, B, ksplit, stream);
 }
 
-// ---- conv weight gradient, NHWC bf16 input: gw[O][c][ky][kx] += sum_m dy[m][o] * im2col(x)[m][k] ---
+// conv, NHWC bf16 input: gw[O][(ky,kx,c)] = sum_m dy[m][o] * im2col(x)[m][k]
 PDA_EXPORT void pda_conv_wgrad(const void* dy, const void* x, void* gw, void* gb, int batch, int H, int W, int C,
-                               int KH, int KW, int S, int O, int ksplit, hipStream_t stream) {
+                               int KH, int KW, int S, int O, long slice_stride, long bslice_stride, int ksplit,
+                               hipStream_t stream) {
     ConvGeom g = make_geom(H, W, C, KH, KW, S);
     int M = batch * g.OH * g.OW, K = C * KH * KW;
     GemmArgs<SrcDenseT, SrcIm2colT, EpiWgrad> a;
     a.g[0].a = {(const bf16_t*)dy, (long)O, O, M};
     a.g[0].b = {(const bf16_t*)x, g, K, M};
-    a.g[0].e = {(float*)gw, (float*)gb, C, KH * KW, (long)K, 1.f};
+    a.g[0].e = {(float*)gw, (float*)gb, (long)K, slice_stride, bslice_stride, 1.f};
     a.g[0].M = O; a.g[0].N = K; a.g[0].K = M;
     if (O <= 32) launch_gemm<32, 64, 1, 4>(a, 1, O, K, M, ksplit, stream);
     else launch_gemm<64, 64, 2, 2>(a, 1, O, K, M, ksplit, stream);
 }
 
-// ---- conv1 weight gradient from uint8 frames (k order (c,ky,kx) == PyTorch's) ----------------------
+// conv1 from uint8 frames: gw[O][(c,ky,kx)] (== PyTorch's own order)
 PDA_EXPORT void pda_conv_wgrad_u8(const void* dy, const void* frames, const void* idx, void* gw, void* gb,
                                   int batch, int H, int W, int C, int KH, int KW, int S, int O, float scale,
-                                  int ksplit, hipStream_t stream) {
+                                  long slice_stride, long bslice_stride, int ksplit, hipStream_t stream) {
     ConvGeom g = make_geom(H, W, C, KH, KW, S);
     int M = batch * g.OH * g.OW, K = C * KH * KW;
     GemmArgs<SrcDenseT, SrcFrameU8T, EpiWgrad> a;
     a.g[0].a = {(const bf16_t*)dy, (long)O, O, M};
     a.g[0].b = {(const uint8_t*)frames, (const int*)idx, (long)C * H * W, g, K, M};
-    a.g[0].e = {(float*)gw, (float*)gb, 1, K, (long)K, scale};   // C=1,P=K: identity column map
+    a.g[0].e = {(float*)gw, (float*)gb, (long)K, slice_stride, bslice_stride, scale};
     a.g[0].M = O; a.g[0].N = K; a.g[0].K = M;
     if (O <= 32) launch_gemm<32, 64, 1, 4>(a, 1, O, K, M, ksplit, stream);
     else launch_gemm<64, 64, 2, 2>(a, 1, O, K, M, ksplit, stream);
+}
+
+// ---- sum split-K slabs into the gradient buffer: dst[e] = sum_s slab[s*stride + e], all jobs in one launch
+struct ReduceJob { const float* slab; float* dst; int count; int nslices; long stride; };
+struct ReduceJobs { ReduceJob j[8]; int first_block[9]; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceJobs jobs, int njobs) {
+    int job = 0;
+    while (job + 1 < njobs && (int)blockIdx.x >= jobs.first_block[job + 1]) ++job;
+    const ReduceJob J = jobs.j[job];
+    int e = ((int)blockIdx.x - jobs.first_block[job]) * 256 + threadIdx.x;
+    if (e >= J.count) return;
+    const float* p = J.slab + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int s = 0;
+    for (; s + 4 <= J.nslices; s += 4) {
+        s0 += p[(long)s * J.stride];
+        s1 += p[(long)(s + 1) * J.stride];
+        s2 += p[(long)(s + 2) * J.stride];
+        s3 += p[(long)(s + 3) * J.stride];
+    }
+    for (; s < J.nslices; ++s) s0 += p[(long)s * J.stride];
+    J.dst[e] = (s0 + s1) + (s2 + s3);
+}
+
+PDA_EXPORT void pda_wgrad_reduce(const void* const* slabs, void* const* dsts, const int* counts, const int* nslices,
+                                 const long* strides, int njobs, hipStream_t stream) {
+    ReduceJobs jobs;
+    int blocks = 0;
+    for (int i = 0; i < njobs && i < 8; ++i) {
+        jobs.j[i] = {(const float*)slabs[i], (float*)dsts[i], counts[i], nslices[i], strides[i]};
+        jobs.first_block[i] = blocks;
+        blocks += (counts[i] + 255) / 256;
+    }
+    jobs.first_block[njobs] = blocks;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, jobs, njobs);
 }
 
 // ---- col2im: fold dcol[(b,oy,ox)][(ky,kx,c)] back onto the NHWC input grid, times act'(y_in) -----

@@ -104,14 +104,12 @@ __global__ void uniform_idx_kernel(int* out_idx, float* out_w, int B, const int*
         if (out_w) out_w[i] = 1.f;
     }
 }
-__global__ void counter_tick_kernel(unsigned long long* counter) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1;
-}
+// (the counter is bumped by a later kernel of the step -- dqn_head_kernel / td_vector_kernel /
+// pda_tick -- never by a kernel that reads it)
 PDA_EXPORT void pda_uniform_idx(void* out_idx, void* out_w, int B, const void* size, unsigned long long seed,
                                 void* counter, hipStream_t stream) {
     hipLaunchKernelGGL(uniform_idx_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, (int*)out_idx,
                        (float*)out_w, B, (const int*)size, seed, (unsigned long long*)counter);
-    hipLaunchKernelGGL(counter_tick_kernel, dim3(1), dim3(64), 0, stream, (unsigned long long*)counter);
 }
 // uniforms[i] in [0,1) for the stratified sampler, same counter scheme
 __global__ void uniform_f32_kernel(float* out, int B, unsigned long long seed, unsigned long long* counter) {
@@ -122,7 +120,6 @@ __global__ void uniform_f32_kernel(float* out, int B, unsigned long long seed, u
 PDA_EXPORT void pda_uniform_f32(void* out, int B, unsigned long long seed, void* counter, hipStream_t stream) {
     hipLaunchKernelGGL(uniform_f32_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, (float*)out, B, seed,
                        (unsigned long long*)counter);
-    hipLaunchKernelGGL(counter_tick_kernel, dim3(1), dim3(64), 0, stream, (unsigned long long*)counter);
 }
 
 // ---- replay: unpack packed transition records into the ring buffers -------------------------

@@ -24,6 +24,7 @@ struct DqnHeadArgs {
     float* q_out; float* td_out; float* loss_sum;
     float* leaf_sum; float* leaf_min; float prio_eps, prio_alpha;
     int B, HID, A;
+    unsigned long long* rng_counter; int* opt_step;     // bumped here (nobody reads them in this launch)
 };
 
 template <int HID>
@@ -31,6 +32,10 @@ __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
     constexpr int PER = HID / 64;       // values per lane (8 for 512)
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int b = blockIdx.x * 4 + wave;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (p.rng_counter) *p.rng_counter += 1;     // the sampler of the NEXT step draws a fresh stream
+        if (p.opt_step) *p.opt_step += 1;           // Adam of THIS step sees t = old + 1
+    }
     if (b >= p.B) return;
     long row = (long)b * HID + lane * PER;
 
@@ -169,8 +174,13 @@ PDA_EXPORT void pda_act_head(const ActHeadArgs* args, hipStream_t stream) {
 __global__ void td_vector_kernel(const float* q, const float* next_q, const float* tails, int tail_ld,
                                  int off_reward, int off_gamma, int off_term, const int* idx, const float* isw,
                                  float* dq, float* td_out, float* loss_sum, float* leaf_sum, float* leaf_min,
-                                 float prio_eps, float prio_alpha, int B) {
+                                 float prio_eps, float prio_alpha, int B, unsigned long long* rng_counter,
+                                 int* opt_step) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) {
+        if (rng_counter) *rng_counter += 1;
+        if (opt_step) *opt_step += 1;
+    }
     float contrib = 0.f;
     if (b < B) {
         int ridx = idx ? idx[b] : b;
@@ -194,27 +204,35 @@ __global__ void td_vector_kernel(const float* q, const float* next_q, const floa
 PDA_EXPORT void pda_td_vector(const void* q, const void* next_q, const void* tails, int tail_ld, int off_reward,
                               int off_gamma, int off_term, const void* idx, const void* isw, void* dq, void* td_out,
                               void* loss_sum, void* leaf_sum, void* leaf_min, float prio_eps, float prio_alpha,
-                              int B, hipStream_t stream) {
+                              int B, void* rng_counter, void* opt_step, hipStream_t stream) {
     hipLaunchKernelGGL(td_vector_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, (const float*)q,
                        (const float*)next_q, (const float*)tails, tail_ld, off_reward, off_gamma, off_term,
                        (const int*)idx, (const float*)isw, (float*)dq, (float*)td_out, (float*)loss_sum,
-                       (float*)leaf_sum, (float*)leaf_min, prio_eps, prio_alpha, B);
+                       (float*)leaf_sum, (float*)leaf_min, prio_eps, prio_alpha, B,
+                       (unsigned long long*)rng_counter, (int*)opt_step);
 }
 
 // ----------------------------------------------------------------------------
 // flat-buffer optimizer.  One launch updates every parameter, clips the gradient
-// by value, zeroes it for the next accumulation and emits the bf16 "shadow"
-// weights in the layout the MFMA kernels read ([row][p*C + c], padded pitch).
+// by value and emits the bf16 "shadow" weights in the layout the MFMA kernels
+// read.  Weights that have a shadow keep their gradient and Adam moments in that
+// same kernel layout ([row][p*C + c]: what the wgrad GEMMs produce with coalesced
+// stores); only the fp32 master stays in PyTorch's layout ([row][c*P + p]).  Threads
+// walk kernel order, so g/m/v/shadow accesses are coalesced and the strided master
+// accesses stay inside one row (<= 12.5 KB), which the vector L1 absorbs.
 // Segment table entry (8 ints): start, count, cols, C, P, shadow_off, shadow_ld, flags(1 = has shadow)
 // hyper (device floats): lr, beta1, beta2, eps, weight_decay, clip, grad_scale
+// step: number of updates including this one (bumped earlier in the step, see dqn_head_kernel / pda_tick)
 // ----------------------------------------------------------------------------
 struct SegEntry { int start, count, cols, C, P, shadow_off, shadow_ld, flags; };
 
-__device__ __forceinline__ void shadow_store(bf16_t* shadow, const SegEntry& s, int e, float v) {
-    if (!(s.flags & 1)) return;
-    int row = e / s.cols, col = e - row * s.cols;
-    int c = col / s.P, pp = col - c * s.P;
-    shadow[(long)s.shadow_off + (long)row * s.shadow_ld + pp * s.C + c] = f2bf(v);
+// kernel-order element j of segment s -> index of its fp32 master
+__device__ __forceinline__ long master_index(const SegEntry& s, int j, long* shadow_idx) {
+    if (!(s.flags & 1)) { *shadow_idx = -1; return (long)s.start + j; }
+    int row = j / s.cols, q = j - row * s.cols;
+    int pp = q / s.C, c = q - pp * s.C;
+    *shadow_idx = (long)s.shadow_off + (long)row * s.shadow_ld + q;
+    return (long)s.start + (long)row * s.cols + c * s.P + pp;
 }
 
 #define OPT_CHUNK 2048      // elements per block
@@ -228,47 +246,57 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     SegEntry s = segs[ch.x];
     float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], clip = hyper[5],
           gscale = hyper[6];
-    float t = (float)(*step + 1);
+    float t = (float)max(*step, 1);
     float bc1 = 1.f - __powf(b1, t), bc2 = 1.f - __powf(b2, t);
     float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
     int end = min(ch.y + OPT_CHUNK, s.count);
     for (int e = ch.y + threadIdx.x; e < end; e += 256) {
+        long si;
+        long ip = master_index(s, e, &si);
         long i = (long)s.start + e;
         float gi = g[i] * gscale;
         gi = fminf(fmaxf(gi, -clip), clip);
-        float pi = p[i];
+        float pi = p[ip];
         gi += wd * pi;
         float mi = b1 * m[i] + (1.f - b1) * gi;
         float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
-        p[i] = pi; m[i] = mi; v[i] = vi; g[i] = 0.f;
-        shadow_store(shadow, s, e, pi);
+        p[ip] = pi; m[i] = mi; v[i] = vi;
+        if (si >= 0) shadow[si] = f2bf(pi);
     }
 }
 
-__global__ void tick_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
+__global__ void tick_kernel(int* step, unsigned long long* counter) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (step) *step += 1;
+        if (counter) *counter += 1;
+    }
+}
+PDA_EXPORT void pda_tick(void* step, void* counter, hipStream_t stream) {
+    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, stream, (int*)step, (unsigned long long*)counter);
+}
 
 PDA_EXPORT void pda_adam(void* p, void* g, void* m, void* v, void* shadow, const void* segs, const void* chunks,
                          int nchunks, const void* hyper, void* step, hipStream_t stream) {
     hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, stream, (float*)p, (float*)g, (float*)m, (float*)v,
                        (bf16_t*)shadow, (const SegEntry*)segs, (const int2*)chunks, (const float*)hyper,
                        (const int*)step);
-    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, stream, (int*)step);
 }
 
-// tgt = (1 - tau) tgt + tau src (tau = 1: hard copy), with the target's shadow weights
-__global__ __launch_bounds__(256) void polyak_kernel(float* __restrict__ tgt, const float* __restrict__ src,
+// tgt = (1 - tau) tgt + tau src (tau >= 1: hard copy) on fp32 masters, with the target's shadow weights
+__global__ __launch_bounds__(256) void polyak_kernel(float* tgt, const float* src,
                                                      bf16_t* __restrict__ shadow, const SegEntry* __restrict__ segs,
                                                      const int2* __restrict__ chunks, float tau) {
     int2 ch = chunks[blockIdx.x];
     SegEntry s = segs[ch.x];
     int end = min(ch.y + OPT_CHUNK, s.count);
     for (int e = ch.y + threadIdx.x; e < end; e += 256) {
-        long i = (long)s.start + e;
+        long si;
+        long i = master_index(s, e, &si);
         float t = tgt[i] + tau * (src[i] - tgt[i]);
         if (tau >= 1.f) t = src[i];
         tgt[i] = t;
-        if (shadow) shadow_store(shadow, s, e, t);
+        if (shadow && si >= 0) shadow[si] = f2bf(t);
     }
 }
 

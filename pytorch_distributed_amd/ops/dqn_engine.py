@@ -13,8 +13,10 @@ the host and a 28.9 MB unpinned H2D copy.  Here one step is a fixed sequence of
               SAME launches; activations bf16 NHWC; fc1 split-K into fp32
   head        fc2 + n-step TD target + (importance-weighted) MSE + dL/dq + fc2
               dgrad + relu mask + PER leaf priorities, one wave64 per sample
-  backward    MFMA wgrad/dgrad GEMMs, fp32 atomics straight into the flat
-              gradient buffer in PyTorch's parameter layout
+  backward    MFMA wgrad/dgrad GEMMs; split-K partial tiles go to scratch slabs
+              with plain coalesced stores (fp32 atomics run memory-side on
+              MI355X: 134 us per conv wgrad in the first profile) and ONE reduce
+              launch sums them into the flat gradient buffer
   (DP)        RCCL all-reduce of the flat gradient: the fc tail (95 % of the
               bytes) is reduced on a side stream while the conv backward runs
   update      one fused clip+Adam launch that also re-emits the bf16 shadow
@@ -54,7 +56,8 @@ class _HeadArgs(ctypes.Structure):     # mirrors DqnHeadArgs in csrc/rl_kernels.
                 ("h1_on0", _vp), ("dh1", _vp), ("dq", _vp), ("dq_ld", ctypes.c_int),
                 ("q_out", _vp), ("td_out", _vp), ("loss_sum", _vp),
                 ("leaf_sum", _vp), ("leaf_min", _vp), ("prio_eps", ctypes.c_float), ("prio_alpha", ctypes.c_float),
-                ("B", ctypes.c_int), ("HID", ctypes.c_int), ("A", ctypes.c_int)]
+                ("B", ctypes.c_int), ("HID", ctypes.c_int), ("A", ctypes.c_int),
+                ("rng_counter", _vp), ("opt_step", _vp)]
 
 
 class _ActArgs(ctypes.Structure):      # mirrors ActHeadArgs
@@ -149,6 +152,26 @@ class CnnWeights(object):
         """Rebuild the bf16 shadows from the fp32 master weights (after a load)."""
         polyak_(self.flat, self.flat, 1.0, self.table, self.shadow)
 
+    def _convert(self, vec, to_kernel):
+        out = vec.clone()
+        shapes = [(32, self.g.K1, 1, self.g.K1), (64, self.g.K2, 32, 16), (64, self.g.K3, 64, 9),
+                  (self.g.HID, self.g.F, 64, self.g.P3)]
+        for layer, (rows, cols, C, P) in zip(self.ORDER[:4], shapes):
+            woff, wn, _, _ = self.off[layer]
+            blk = vec[woff:woff + wn]
+            if to_kernel:       # [row][c*P+p] -> [row][p*C+c]
+                out[woff:woff + wn] = blk.view(rows, C, P).permute(0, 2, 1).reshape(-1)
+            else:
+                out[woff:woff + wn] = blk.view(rows, P, C).permute(0, 2, 1).reshape(-1)
+        return out
+
+    def to_kernel_layout(self, vec):
+        """Flat vector in PyTorch parameter layout -> the layout gradients/moments use here."""
+        return self._convert(vec, True)
+
+    def to_torch_layout(self, vec):
+        return self._convert(vec, False)
+
     def grad_views(self, flat_grads):
         gw, gb = [], []
         for layer in self.ORDER:
@@ -212,6 +235,7 @@ class DqnCnnEngine(object):
                              clip=clip, shadow=self.online.shadow)
         self.groups = 3 if self.double else 2
         self.acts = _Acts(g, self.B, self.groups, dev, backward=True)
+        self._plan_wgrads()
         self.idx = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self.isw = torch.ones(self.B, dtype=torch.float32, device=dev)
         self.uniforms = torch.zeros(self.B, dtype=torch.float32, device=dev)
@@ -228,6 +252,31 @@ class DqnCnnEngine(object):
         # the tail bucket [fc1.weight .. end] is ready right after the two fc wgrads
         self.tail_start = self.online.off["critic.1.0"][0]
         polyak_(self.target.flat, self.online.flat, 1.0, self.target.table, self.target.shadow)   # hard copy to start
+
+    def _plan_wgrads(self):
+        """Split-K plan of the three conv weight gradients: slab sizes + the one reduce launch."""
+        g, B, dev = self.geom, self.B, self.device
+        plans = []      # (layer, O, K, red)
+        for li, (O, K, red) in enumerate([(32, g.K1, B * g.H1 * g.W1), (64, g.K2, B * g.H2 * g.W2),
+                                          (64, g.K3, B * g.P3)]):
+            tiles = ((O + 63) // 64 if O > 32 else 1) * ((K + 63) // 64)
+            ks = _ksplit(red, tiles, 512, 128)
+            ns = nn.num_slices(red, ks)
+            plans.append((li, O, K, ks, ns))
+        self.wg_plan = plans
+        total = sum(ns * (O * K + O) for _, O, K, _, ns in plans)
+        self.slab = torch.zeros(total, dtype=torch.float32, device=dev)
+        jobs, off = [], 0
+        self.wg_slabs = []
+        for li, O, K, ks, ns in plans:
+            w = self.slab[off:off + ns * O * K]
+            off += ns * O * K
+            b = self.slab[off:off + ns * O]
+            off += ns * O
+            self.wg_slabs.append((w, b, ks, O * K, O))
+            jobs.append((w, self.gw[li], O * K, ns, O * K))
+            jobs.append((b, self.gb[li], O, ns, O))
+        self.reduce = nn.ReducePlan(jobs)
 
     # ---- data sources --------------------------------------------------------------------------
     def bind_replay(self, state0s, state1s, tails, tree=None):
@@ -280,33 +329,41 @@ class DqnCnnEngine(object):
             leaf_sum=_p(tree.sum) if tree is not None else 0, leaf_min=_p(tree.min) if tree is not None else 0,
             prio_eps=float(self.per["eps"]) if self.per else 0.0,
             prio_alpha=float(self.per["alpha"]) if self.per else 1.0,
-            B=B, HID=g.HID, A=g.A)
+            B=B, HID=g.HID, A=g.A, rng_counter=_p(self.counter), opt_step=_p(self.adam.step_dev))
         _L().pda_dqn_head(ctypes.byref(args), _stream())
 
     def backward_fc(self):
         g, B, a = self.geom, self.B, self.acts
+        # one slice each: written straight into the gradient buffer (kernel layout)
         nn.linear_wgrad(a.dq, a.h1, self.gw[4], self.gb[4], B, g.A, g.HID, a.dq_ld, g.HID, g.HID)
-        nn.linear_wgrad(a.dh1, a.a3[0], self.gw[3], self.gb[3], B, g.HID, g.F, g.HID, g.F, g.F, C=64, P=g.P3)
+        nn.linear_wgrad(a.dh1, a.a3[0], self.gw[3], self.gb[3], B, g.HID, g.F, g.HID, g.F, g.F)
 
     def backward_conv(self, staged=False):
         g, B, a = self.geom, self.B, self.acts
         s0, _, _, idx, _ = self._sources(staged)
         on = self.online
-        M3, M2, M1 = B * g.P3, B * g.H2 * g.W2, B * g.H1 * g.W1
+        M3, M2 = B * g.P3, B * g.H2 * g.W2
+        (w1s, b1s, ks1, st1, bst1), (w2s, b2s, ks2, st2, bst2), (w3s, b3s, ks3, st3, bst3) = self.wg_slabs
         nn.linear_dgrad(a.dh1, on.w[3], a.a3[0], a.da3, B, g.HID, g.F, g.HID, g.F, g.F, g.F, act=nn.ACT_RELU)
-        nn.conv_wgrad(a.da3, a.a2[0], self.gw[2], self.gb[2], B, g.H2, g.W2, 64, 3, 3, 1, 64,
-                      ksplit=_ksplit(M3, (g.K3 + 63) // 64))
+        nn.conv_wgrad(a.da3, a.a2[0], w3s, b3s, B, g.H2, g.W2, 64, 3, 3, 1, 64, ksplit=ks3, slice_stride=st3,
+                      bslice_stride=bst3)
         nn.linear_dgrad(a.da3, on.w[2], None, a.dcol3, M3, 64, g.K3, 64, g.K3, 0, g.K3)
         nn.col2im(a.dcol3, a.a2[0], a.da2, B, g.H2, g.W2, 64, 3, 3, 1, act=nn.ACT_RELU)
-        nn.conv_wgrad(a.da2, a.a1[0], self.gw[1], self.gb[1], B, g.H1, g.W1, 32, 4, 4, 2, 64,
-                      ksplit=_ksplit(M2, (g.K2 + 63) // 64))
+        nn.conv_wgrad(a.da2, a.a1[0], w2s, b2s, B, g.H1, g.W1, 32, 4, 4, 2, 64, ksplit=ks2, slice_stride=st2,
+                      bslice_stride=bst2)
         nn.linear_dgrad(a.da2, on.w[1], None, a.dcol2, M2, 64, g.K2, 64, g.K2, 0, g.K2)
         nn.col2im(a.dcol2, a.a1[0], a.da1, B, g.H1, g.W1, 32, 4, 4, 2, act=nn.ACT_RELU)
-        nn.conv_wgrad_u8(a.da1, s0, idx, self.gw[0], self.gb[0], B, g.H, g.W, g.C, 8, 8, 4, 32,
-                         1.0 / self.norm_val, ksplit=_ksplit(M1, (g.K1 + 63) // 64))
+        nn.conv_wgrad_u8(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / self.norm_val,
+                         ksplit=ks1, slice_stride=st1, bslice_stride=bst1)
+        self.reduce.run()
 
-    def update(self, staged=False):
-        self.adam.step()
+    def grads_torch_layout(self):
+        """The flat gradient re-ordered to PyTorch's parameter layout (tests, debugging)."""
+        return self.online.to_torch_layout(self.grads)
+
+    def update(self, staged=False, tick=False):
+        """tick: bump Adam's step counter here (the head kernel does it in a full step)."""
+        self.adam.step(tick=tick)
         if self.target_update < 1.0:
             polyak_(self.target.flat, self.online.flat, float(self.target_update), self.target.table,
                     self.target.shadow)

@@ -47,13 +47,14 @@ def _L():
         L.pda_conv_fwd.argtypes = [_vp] * 4 + [c_int] * 10 + [_vp]
         L.pda_linear_fwd.argtypes = [_vp] * 5 + [c_int] * 4 + [c_long] * 4 + [c_int, c_int, _vp]
         L.pda_linear_dgrad.argtypes = [_vp] * 4 + [c_int] * 3 + [c_long] * 4 + [c_int, _vp]
-        L.pda_linear_wgrad.argtypes = [_vp] * 4 + [c_int] * 3 + [c_long] * 3 + [c_int, c_int, c_float, c_int, _vp]
-        L.pda_conv_wgrad.argtypes = [_vp] * 4 + [c_int] * 9 + [_vp]
-        L.pda_conv_wgrad_u8.argtypes = [_vp] * 5 + [c_int] * 8 + [c_float, c_int, _vp]
+        L.pda_linear_wgrad.argtypes = [_vp] * 4 + [c_int] * 3 + [c_long] * 5 + [c_float, c_int, _vp]
+        L.pda_conv_wgrad.argtypes = [_vp] * 4 + [c_int] * 8 + [c_long, c_long, c_int, _vp]
+        L.pda_conv_wgrad_u8.argtypes = [_vp] * 5 + [c_int] * 8 + [c_float, c_long, c_long, c_int, _vp]
+        L.pda_wgrad_reduce.argtypes = [_vp] * 5 + [c_int, _vp]
         L.pda_col2im.argtypes = [_vp] * 3 + [c_int] * 8 + [_vp]
         L.pda_tr_probe.argtypes = [_vp, _vp]
         for name in ("pda_conv_fwd_u8", "pda_conv_fwd", "pda_linear_fwd", "pda_linear_dgrad", "pda_linear_wgrad",
-                     "pda_conv_wgrad", "pda_conv_wgrad_u8", "pda_col2im", "pda_tr_probe"):
+                     "pda_conv_wgrad", "pda_conv_wgrad_u8", "pda_col2im", "pda_tr_probe", "pda_wgrad_reduce"):
             getattr(L, name).restype = None
         _configured = True
     return L
@@ -89,21 +90,54 @@ def linear_dgrad(dy, w, y, dx, M, Nout, Kin, lddy, ldw, ldy, lddx, act=ACT_NONE)
     _L().pda_linear_dgrad(_ptr(dy), _ptr(w), _ptr(y), _ptr(dx), M, Nout, Kin, lddy, ldw, ldy, lddx, act, _stream())
 
 
-def linear_wgrad(dy, x, gw, gb, B, Nout, Kin, lddy, ldx, ldg, C=1, P=None, scale=1.0, ksplit=0):
-    """gw[Nout][perm(Kin)] += dy[B][Nout]^T @ x[B][Kin]; gb[Nout] += column sums of dy.
-    Column k = p*C + c of x lands at gw column c*P + p (C=1: identity)."""
+def num_slices(red, ksplit):
+    """Split-K slices a launch with this ksplit produces over a reduction of length red."""
+    if ksplit <= 0:
+        return 1
+    ks = (ksplit + 31) // 32 * 32
+    return (red + ks - 1) // ks
+
+
+def linear_wgrad(dy, x, gw, gb, B, Nout, Kin, lddy, ldx, ldg, scale=1.0, ksplit=0, slice_stride=0, bslice_stride=0):
+    """Slice y of gw[Nout][Kin] = dy[B][Nout]^T @ x[B][Kin] over its share of B -> gw + y*slice_stride,
+    column sums of dy -> gb + y*bslice_stride (plain stores, GEMM layout).  ksplit=0: one slice."""
     assert lddy % 8 == 0 and ldx % 8 == 0
-    _L().pda_linear_wgrad(_ptr(dy), _ptr(x), _ptr(gw), _ptr(gb), B, Nout, Kin, lddy, ldx, ldg, C,
-                          Kin if P is None else P, float(scale), ksplit, _stream())
+    assert ksplit == 0 or slice_stride >= Nout * ldg
+    _L().pda_linear_wgrad(_ptr(dy), _ptr(x), _ptr(gw), _ptr(gb), B, Nout, Kin, lddy, ldx, ldg,
+                          slice_stride, bslice_stride, float(scale), ksplit, _stream())
 
 
-def conv_wgrad(dy, x, gw, gb, batch, H, W, C, KH, KW, S, O, ksplit=0):
-    _L().pda_conv_wgrad(_ptr(dy), _ptr(x), _ptr(gw), _ptr(gb), batch, H, W, C, KH, KW, S, O, ksplit, _stream())
+def conv_wgrad(dy, x, gw, gb, batch, H, W, C, KH, KW, S, O, ksplit=0, slice_stride=0, bslice_stride=0):
+    """gw[O][(ky,kx,c)] slices (see linear_wgrad); x is NHWC bf16."""
+    assert ksplit == 0 or slice_stride >= O * C * KH * KW
+    _L().pda_conv_wgrad(_ptr(dy), _ptr(x), _ptr(gw), _ptr(gb), batch, H, W, C, KH, KW, S, O,
+                        slice_stride, bslice_stride, ksplit, _stream())
 
 
-def conv_wgrad_u8(dy, frames, idx, gw, gb, batch, H, W, C, KH, KW, S, O, scale, ksplit=0):
+def conv_wgrad_u8(dy, frames, idx, gw, gb, batch, H, W, C, KH, KW, S, O, scale, ksplit=0, slice_stride=0,
+                  bslice_stride=0):
+    assert ksplit == 0 or slice_stride >= O * C * KH * KW
     _L().pda_conv_wgrad_u8(_ptr(dy), _ptr(frames), _ptr(idx), _ptr(gw), _ptr(gb), batch, H, W, C, KH, KW, S, O,
-                           float(scale), ksplit, _stream())
+                           float(scale), slice_stride, bslice_stride, ksplit, _stream())
+
+
+class ReducePlan(object):
+    """Host-side argument block for pda_wgrad_reduce: dst[e] = sum_s slab[s*stride + e] for up to 8 jobs."""
+
+    def __init__(self, jobs):
+        """jobs: [(slab tensor, dst tensor, count, nslices, stride)]"""
+        assert 0 < len(jobs) <= 8
+        n = len(jobs)
+        self.keep = jobs
+        self.slabs = (_vp * n)(*[j[0].data_ptr() for j in jobs])
+        self.dsts = (_vp * n)(*[j[1].data_ptr() for j in jobs])
+        self.counts = (ctypes.c_int * n)(*[int(j[2]) for j in jobs])
+        self.nslices = (ctypes.c_int * n)(*[int(j[3]) for j in jobs])
+        self.strides = (ctypes.c_long * n)(*[int(j[4]) for j in jobs])
+        self.n = n
+
+    def run(self):
+        _L().pda_wgrad_reduce(self.slabs, self.dsts, self.counts, self.nslices, self.strides, self.n, _stream())
 
 
 def col2im(dcol, yin, dx, batch, H, W, C, KH, KW, S, act=ACT_RELU):

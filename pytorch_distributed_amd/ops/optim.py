@@ -1,9 +1,9 @@
 """Flat-buffer optimizer / target-update kernels (K13-K15): python bindings.
 
 `FlatAdam` drives csrc/rl_kernels.hip:adam_kernel: ONE launch clips the gradient
-by value, applies Adam to every parameter of a model's flat fp32 buffer, zeroes
-the gradient for the next accumulation and re-emits the bf16 "shadow" weights in
-the layouts the MFMA kernels read.  Hyper-parameters and the step counter live
+by value, applies Adam to every parameter of a model's flat fp32 buffer and
+re-emits the bf16 "shadow" weights in the layouts the MFMA kernels read.
+Gradients and moments of shadowed weights are kept in that kernel layout.  Hyper-parameters and the step counter live
 in device memory so the launch can sit inside a captured hipGraph.
 `polyak_` is the fused hard/soft target update (reference utils/helpers.py:19-25
 loops over parameters in Python).
@@ -62,11 +62,17 @@ class FlatAdam(object):
         L = lib()
         L.pda_adam.argtypes = [_vp] * 7 + [ctypes.c_int, _vp, _vp, _vp]
         L.pda_adam.restype = None
+        L.pda_tick.argtypes = [_vp, _vp, _vp]
+        L.pda_tick.restype = None
 
     def set_lr(self, lr):
         self.hyper[0] = float(lr)
 
-    def step(self):
+    def step(self, tick=False):
+        """tick=True bumps the step counter with an extra tiny launch; engines whose
+        loss kernel already bumps it (dqn_head / td_vector) pass False."""
+        if tick:
+            lib().pda_tick(_p(self.step_dev), _vp(0), _stream())
         lib().pda_adam(_p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.shadow), _p(self.table.segs),
                        _p(self.table.chunks), self.table.nchunks, _p(self.hyper), _p(self.step_dev), _stream())
 

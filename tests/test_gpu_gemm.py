@@ -108,19 +108,23 @@ def test_linear_dgrad_and_wgrad(nn):
     close(dx, (dy @ w) * (y > 0))
     nn.linear_dgrad(dy.bfloat16(), w.bfloat16(), y.bfloat16(), dx, B, Nout, Kin, Nout, Kin, Kin, Kin, act=nn.ACT_TANH)
     close(dx, (dy @ w) * (1 - y * y))
-    gw = torch.zeros(Nout, Kin, device="cuda")
-    gb = torch.zeros(Nout, device="cuda")
-    nn.linear_wgrad(dy.bfloat16(), x.bfloat16(), gw, gb, B, Nout, Kin, Nout, Kin, Kin, C=C, P=P)
-    ref = (dy.t() @ x).reshape(Nout, P, C).permute(0, 2, 1).reshape(Nout, Kin)   # (p,c) -> PyTorch (c,p)
-    close(gw, ref, 1e-3, 1e-3)
+    gw = torch.full((Nout, Kin), 7.0, device="cuda")       # plain stores: stale contents must vanish
+    gb = torch.full((Nout,), 7.0, device="cuda")
+    nn.linear_wgrad(dy.bfloat16(), x.bfloat16(), gw, gb, B, Nout, Kin, Nout, Kin, Kin)
+    close(gw, dy.t() @ x, 1e-3, 1e-3)
     close(gb, dy.sum(0), 1e-3, 1e-3)
     # small-M instance (fc2: 6 actions padded to 16 columns), split-K over the batch
     dq = torch.zeros(B, 16, device="cuda")
     dq[:, :6] = bf(torch.randn(B, 6, device="cuda"))
     h = bf(torch.randn(B, 512, device="cuda"))
+    ns = nn.num_slices(B, 64)
+    slab = torch.full((ns, 6 * 512), 7.0, device="cuda")
+    bslab = torch.full((ns, 6), 7.0, device="cuda")
+    nn.linear_wgrad(dq.bfloat16(), h.bfloat16(), slab, bslab, B, 6, 512, 16, 512, 512, ksplit=64,
+                    slice_stride=6 * 512, bslice_stride=6)
     gw2 = torch.zeros(6, 512, device="cuda")
     gb2 = torch.zeros(6, device="cuda")
-    nn.linear_wgrad(dq.bfloat16(), h.bfloat16(), gw2, gb2, B, 6, 512, 16, 512, 512, ksplit=64)
+    nn.ReducePlan([(slab, gw2, 6 * 512, ns, 6 * 512), (bslab, gb2, 6, ns, 6)]).run()
     close(gw2, dq[:, :6].t() @ h, 1e-3, 1e-3)
     close(gb2, dq[:, :6].sum(0), 1e-3, 1e-3)
 
@@ -137,13 +141,18 @@ def test_conv_backward_nhwc(nn, geom):
     dy = bf(torch.randn(batch, O, OH, OW, device="cuda"))
     F.conv2d(x, w, b, stride=S).backward(dy)
     # weight / bias gradient
-    gw = torch.zeros(O, C, KH, KW, device="cuda")
+    K = C * KH * KW
+    ns = nn.num_slices(batch * OH * OW, 256)
+    slab = torch.full((ns, O * K), 7.0, device="cuda")
+    bslab = torch.full((ns, O), 7.0, device="cuda")
+    nn.conv_wgrad(nn.nhwc(dy), nn.nhwc(x.detach()), slab, bslab, batch, H, W, C, KH, KW, S, O, ksplit=256,
+                  slice_stride=O * K, bslice_stride=O)
+    gw = torch.zeros(O, KH, KW, C, device="cuda")            # kernel layout (ky, kx, c)
     gb = torch.zeros(O, device="cuda")
-    nn.conv_wgrad(nn.nhwc(dy), nn.nhwc(x.detach()), gw, gb, batch, H, W, C, KH, KW, S, O, ksplit=256)
-    close(gw, w.grad, 2e-3, 2e-3)
+    nn.ReducePlan([(slab, gw, O * K, ns, O * K), (bslab, gb, O, ns, O)]).run()
+    close(gw.permute(0, 3, 1, 2), w.grad, 2e-3, 2e-3)
     close(gb, b.grad, 2e-3, 2e-3)
     # data gradient = dcol GEMM + col2im (masked by relu of the layer input)
-    K = C * KH * KW
     M = batch * OH * OW
     dcol = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
     nn.linear_dgrad(nn.nhwc(dy), nn.pack_conv_weight(w), None, dcol, M, O, K, O, K, 0, K)
@@ -162,8 +171,13 @@ def test_conv1_wgrad_u8(nn):
     b = torch.zeros(32, device="cuda", requires_grad=True)
     dy = bf(torch.randn(batch, 32, 20, 20, device="cuda"))
     F.conv2d(x, w, b, stride=4).backward(dy)
+    ns = nn.num_slices(batch * 400, 512)
+    slab = torch.full((ns, 32 * 256), 7.0, device="cuda")
+    bslab = torch.full((ns, 32), 7.0, device="cuda")
+    nn.conv_wgrad_u8(nn.nhwc(dy), mem, idx, slab, bslab, batch, 84, 84, 4, 8, 8, 4, 32, 1.0 / 255.0, ksplit=512,
+                     slice_stride=32 * 256, bslice_stride=32)
     gw = torch.zeros(32, 256, device="cuda")
     gb = torch.zeros(32, device="cuda")
-    nn.conv_wgrad_u8(nn.nhwc(dy), mem, idx, gw, gb, batch, 84, 84, 4, 8, 8, 4, 32, 1.0 / 255.0, ksplit=512)
+    nn.ReducePlan([(slab, gw, 32 * 256, ns, 32 * 256), (bslab, gb, 32, ns, 32)]).run()
     close(gw.reshape(32, 4, 8, 8), w.grad, 2e-3, 2e-3)
     close(gb, b.grad, 2e-3, 2e-3)
