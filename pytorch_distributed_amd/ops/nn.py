@@ -9,7 +9,8 @@ Layouts
   activations   bf16, NHWC flattened to [rows = (b, y, x)][channels]
   conv weights  bf16 "shadow" copies [O][(ky, kx, c)]  (conv1: [O][(c, ky, kx)] = PyTorch's)
   fc weights    bf16 [N][K], K permuted to the NHWC flatten order where needed
-  gradients     fp32, written in PyTorch's own parameter layout (atomicAdd)
+  gradients     fp32, plain stores in the same (kernel) layout as the bf16 weights; split-K
+                launches write partial slabs that ReducePlan sums
 """
 import ctypes
 
@@ -77,7 +78,9 @@ def conv_fwd(x, w, bias, out, batch, H, W, C, KH, KW, S, O, act=ACT_RELU):
 
 
 def linear_fwd(x, w, bias, out, out32, M, N, K, ldx, ldw, ldo=0, ldo32=0, act=ACT_NONE, ksplit=0):
-    assert K % 8 == 0 and ldx % 8 == 0 and ldw % 8 == 0 and len(x) <= 3
+    # K need not be a multiple of 8, but then the pad columns (up to the next multiple of 8,
+    # inside ldx / ldw) of x AND w must be zero: the loaders fetch 8 k at a time
+    assert ldx % 8 == 0 and ldw % 8 == 0 and ldx >= (K + 7) // 8 * 8 and ldw >= (K + 7) // 8 * 8 and len(x) <= 3
     n = len(x)
     _L().pda_linear_fwd(_arr(x), _arr(w), _arr(bias if bias else [None] * n), _arr(out if out else [None] * n),
                         _arr(out32 if out32 else [None] * n), n, M, N, K, ldx, ldw, ldo, ldo32, act, ksplit,
@@ -85,8 +88,10 @@ def linear_fwd(x, w, bias, out, out32, M, N, K, ldx, ldw, ldo=0, ldo32=0, act=AC
 
 
 def linear_dgrad(dy, w, y, dx, M, Nout, Kin, lddy, ldw, ldy, lddx, act=ACT_NONE):
-    """dx[M][Kin] = (dy[M][Nout] @ w[Nout][Kin]) * act'(y[M][Kin]) (y None: no mask)."""
-    assert Nout % 8 == 0 and Kin % 8 == 0 and lddy % 8 == 0 and ldw % 8 == 0
+    """dx[M][Kin] = (dy[M][Nout] @ w[Nout][Kin]) * act'(y[M][Kin]) (y None: no mask).
+    Nout / Kin need not be multiples of 8 when the pad columns of dy (inside lddy) are zero
+    and ldw covers Kin rounded up to 8."""
+    assert lddy % 8 == 0 and ldw % 8 == 0 and lddy >= (Nout + 7) // 8 * 8 and ldw >= (Kin + 7) // 8 * 8
     _L().pda_linear_dgrad(_ptr(dy), _ptr(w), _ptr(y), _ptr(dx), M, Nout, Kin, lddy, ldw, ldy, lddx, act, _stream())
 
 

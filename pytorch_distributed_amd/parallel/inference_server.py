@@ -120,6 +120,9 @@ class BatchedPolicy(object):
             if ops.native_available() and args.model_type == "dqn-cnn":
                 from ..ops.dqn_engine import DqnCnnInference
                 self.engine = DqnCnnInference(model, max_batch=max(args.num_actors, 1))
+            elif ops.native_available() and args.model_type == "ddpg-mlp":
+                from ..ops.mlp_engine import DdpgActorInference
+                self.engine = DdpgActorInference(model, max_batch=max(args.num_actors, 1))
 
     def refresh(self):
         if self.engine is not None:
@@ -141,7 +144,10 @@ class BatchedPolicy(object):
                 a = torch.where(explore, rand_a, greedy)
                 q = qv.gather(1, a[:, None])[:, 0]
             return a.float().cpu().numpy().reshape(n, 1), q.cpu().numpy(), mq.cpu().numpy()
-        act = self.model.forward_actor(obs)
+        if self.engine is not None:
+            act = self.engine.act(obs)
+        else:
+            act = self.model.forward_actor(obs)
         z = np.zeros(n, dtype=np.float32)
         return act.float().cpu().numpy(), z, z
 
