@@ -1,0 +1,231 @@
+"""Data-parallel learner path without a GPU: FakeComm (in-process), TorchComm over
+gloo with 2 spawned ranks, and a 2-learner job through the launcher.  The same
+TorchComm class runs RCCL on the MI355X node (backend "nccl")."""
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from pytorch_distributed_amd.agents.learners import DqnTorchCore, DdpgTorchCore
+from pytorch_distributed_amd.launcher import prepare_options, run
+from pytorch_distributed_amd.parallel.comm import FakeComm, SingleComm, TorchComm, make_comm
+from pytorch_distributed_amd.utils.factory import ModelsDict
+from pytorch_distributed_amd.utils.options import Options
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class FixedBatchMemory(object):
+    """Replays a fixed list of batches; what a rank's replay shard would hand out."""
+    enable_per = False
+
+    def __init__(self, batches):
+        self.batches, self.i = batches, 0
+
+    def sample_with_priorities(self, batch_size):
+        b = self.batches[self.i % len(self.batches)]
+        self.i += 1
+        assert b[0].shape[0] == batch_size
+        return b, None, torch.ones(batch_size, 1)
+
+    def update_priorities(self, inds, td):
+        pass
+
+
+def _dqn_batches(n, B, D, A, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        out.append((torch.randn(B, 1, D, generator=g), torch.randint(0, A, (B, 1), generator=g).float(),
+                    torch.randn(B, 1, generator=g), torch.full((B, 1), 0.97), torch.randn(B, 1, D, generator=g),
+                    (torch.rand(B, 1, generator=g) < 0.2).float()))
+    return out
+
+
+def _same_params(a, b, lr=1e-3, steps=5):
+    """Equal up to fp32 summation order.  Adam divides by |g|, so the handful of elements whose
+    gradient is ~1e-8 may move differently by up to lr per step; everything else must agree."""
+    d = (a - b).abs()
+    return d.max().item() <= 2.5 * lr * steps and (d > 2e-6).float().mean().item() < 1e-3
+
+
+def _split(batch, world):
+    parts = [torch.chunk(t, world, dim=0) for t in batch]
+    return [tuple(p[r] for p in parts) for r in range(world)]
+
+
+def _mlp_opt(B):
+    opt = Options(config=6, overrides={"device": "cpu", "agent_params.batch_size": B, "agent_params.lr": 1e-3,
+                                       "agent_params.target_model_update": 2})
+    return prepare_options(opt)
+
+
+def test_single_comm_is_identity():
+    c = SingleComm()
+    t = torch.arange(4.0)
+    c.all_reduce_mean_(t)
+    assert torch.equal(t, torch.arange(4.0)) and c.all_agree(True) and not c.all_agree(False)
+
+
+def test_fake_comm_collectives():
+    comms = FakeComm.create(4)
+    ts = [torch.full((3,), float(r)) for r in range(4)]
+    for c, t in zip(comms, ts):
+        c.all_reduce_mean_(t)
+    assert all(torch.allclose(t, torch.full((3,), 1.5)) for t in ts)
+    ts = [torch.full((3,), float(r + 1)) for r in range(4)]
+    for c, t in zip(comms, ts):
+        c.broadcast_(t, src=0)
+    assert all(torch.equal(t, torch.ones(3)) for t in ts)
+
+
+def test_dp_two_ranks_equal_one_rank_with_double_batch():
+    """Synchronous DP: 2 ranks x B/2 with the gradient mean == 1 rank x B (reference has only Hogwild)."""
+    B, world, steps = 16, 2, 5
+    opt = _mlp_opt(B)
+    D, A = int(np.prod(opt.state_shape)), opt.action_space
+    full = _dqn_batches(steps, B, D, A, seed=3)
+    torch.manual_seed(0)
+    proto = ModelsDict[opt.model_type](opt.model_params, opt.norm_val, opt.state_shape, opt.action_space,
+                                       opt.action_shape)
+    single = DqnTorchCore(opt, copy.deepcopy(proto), copy.deepcopy(proto), FixedBatchMemory(full), SingleComm())
+    opt_half = _mlp_opt(B // world)
+    comms = FakeComm.create(world)
+    ranks = []
+    for r in range(world):
+        shard = [_split(b, world)[r] for b in full]
+        ranks.append(DqnTorchCore(opt_half, copy.deepcopy(proto), copy.deepcopy(proto), FixedBatchMemory(shard),
+                                  comms[r]))
+    # FakeComm finishes a collective when the last rank arrives, so run the ranks' steps in
+    # lock-step threads-free fashion: interleave by monkeypatching _finish to defer after all backward passes
+    for _ in range(steps):
+        single.step()
+        pending = []
+        for core in ranks:
+            orig = core._finish
+            core._finish = lambda td, inds, _c=core: pending.append((_c, td, inds))
+            core.step()
+            core._finish = orig
+        for core, td, inds in pending:
+            core.comm.all_reduce_mean_(core.model.flat_grads)
+        for core, td, inds in pending:
+            comm, core.comm = core.comm, SingleComm()
+            core._finish(td, inds)
+            core.comm = comm
+    ref = single.model.flat_params
+    for core in ranks:
+        assert _same_params(core.model.flat_params, ref), (core.model.flat_params - ref).abs().max()
+        assert _same_params(core.target_model.flat_params, single.target_model.flat_params)
+
+
+def _gloo_worker(rank, world, port, out_q):
+    comm = TorchComm(rank, world, torch.device("cpu"), init_method="tcp://127.0.0.1:%d" % port)
+    t = torch.full((1000,), float(rank + 1))
+    comm.all_reduce_mean_(t)
+    ok_mean = bool(torch.allclose(t, torch.full((1000,), (world + 1) / 2.0)))
+    s = torch.arange(10.0) * (rank + 1)
+    comm.all_reduce_sum_(s)
+    ok_sum = bool(torch.allclose(s, torch.arange(10.0) * sum(range(1, world + 1))))
+    w = torch.full((64,), float(rank * 7 + 3))
+    comm.broadcast_(w, src=0)
+    ok_bc = bool(torch.equal(w, torch.full((64,), 3.0)))
+    agree_all = comm.all_agree(True)
+    agree_one = comm.all_agree(rank == 0)
+    comm.barrier()
+    # a DP learner step through the real process group: 2 ranks x 8 == 1 rank x 16
+    B = 16
+    opt = _mlp_opt(B // world)
+    D, A = int(np.prod(opt.state_shape)), opt.action_space
+    full = _dqn_batches(3, B, D, A, seed=11)
+    torch.manual_seed(0)
+    proto = ModelsDict[opt.model_type](opt.model_params, opt.norm_val, opt.state_shape, opt.action_space,
+                                       opt.action_shape)
+    core = DqnTorchCore(opt, copy.deepcopy(proto), copy.deepcopy(proto),
+                        FixedBatchMemory([_split(b, world)[rank] for b in full]), comm)
+    for _ in range(3):
+        core.step()
+    flat = core.model.flat_params.clone()
+    ref_core = DqnTorchCore(_mlp_opt(B), copy.deepcopy(proto), copy.deepcopy(proto), FixedBatchMemory(full),
+                            SingleComm())
+    for _ in range(3):
+        ref_core.step()
+    ok_dp = _same_params(flat, ref_core.model.flat_params)
+    out_q.put((rank, ok_mean, ok_sum, ok_bc, agree_all, agree_one, ok_dp))
+    comm.close()
+
+
+def test_torch_comm_gloo_two_ranks():
+    world, port = 2, free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok_mean, ok_sum, ok_bc, agree_all, agree_one, ok_dp in results:
+        assert ok_mean and ok_sum and ok_bc and ok_dp, (rank, ok_mean, ok_sum, ok_bc, ok_dp)
+        assert agree_all is True and agree_one is False
+
+
+def test_make_comm_world_one_is_single():
+    assert isinstance(make_comm(0, 1, torch.device("cpu")), SingleComm)
+
+
+def test_two_learner_job_through_launcher(tmp_root):
+    """num_learners=2: two learner processes form a gloo group, rank 0 publishes."""
+    from tests.test_integration import FAST
+    o = dict(FAST)
+    o.update({"root_dir": tmp_root, "timestamp": "dp2", "num_learners": 2, "num_actors": 2,
+              "dist_port": free_port(), "agent_params.steps": 25, "agent_params.learn_start": 60})
+    opt = Options(config=6, overrides=o)
+    sup = run(opt)
+    assert all(c == 0 for c in sup.exitcodes), sup.exitcodes
+    assert os.path.exists(opt.model_name)
+
+
+def test_ddpg_dp_equivalence_fake_comm():
+    B, world = 8, 2
+    opt = prepare_options(Options(config=3, overrides={"device": "cpu", "agent_params.batch_size": B,
+                                                       "agent_params.lr": 1e-3}))
+    D, A = int(np.prod(opt.state_shape)), int(opt.action_shape)
+    g = torch.Generator().manual_seed(5)
+    full = [(torch.randn(B, 1, D, generator=g), torch.rand(B, A, generator=g) * 2 - 1, torch.randn(B, 1, generator=g),
+             torch.full((B, 1), 0.95), torch.randn(B, 1, D, generator=g), torch.zeros(B, 1))]
+    torch.manual_seed(1)
+    proto = ModelsDict[opt.model_type](opt.model_params, opt.norm_val, opt.state_shape, opt.action_space,
+                                       opt.action_shape)
+    single = DdpgTorchCore(opt, copy.deepcopy(proto), copy.deepcopy(proto), FixedBatchMemory(full), SingleComm())
+    single.step()
+    opt_h = prepare_options(Options(config=3, overrides={"device": "cpu", "agent_params.batch_size": B // world,
+                                                         "agent_params.lr": 1e-3}))
+    comms = FakeComm.create(world)
+    cores, pending = [], []
+    for r in range(world):
+        core = DdpgTorchCore(opt_h, copy.deepcopy(proto), copy.deepcopy(proto),
+                             FixedBatchMemory([_split(full[0], world)[r]]), comms[r])
+        core._finish_real = core._finish
+        core._finish = lambda td, inds, _c=core: pending.append((_c, td, inds))
+        core.step()
+        cores.append(core)
+    for core, td, inds in pending:
+        core.comm.all_reduce_mean_(core.model.flat_grads)
+    for core, td, inds in pending:
+        core.comm = SingleComm()
+        core._finish_real(td, inds)
+    # value-clip happens per rank before the mean in DP, after it on one rank: identical while no
+    # gradient element reaches the clip (40), which holds for this data
+    for core in cores:
+        assert _same_params(core.model.flat_params, single.model.flat_params)
