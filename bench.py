@@ -43,15 +43,23 @@ def main():
     ap.add_argument("--config", type=int, default=2, help="options.CONFIGS row (2 uniform, 4 Ape-X PER)")
     ap.add_argument("--compute", default="native", choices=["native", "torch"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--backend", default=None, help="process-group backend override (default: nccl = RCCL)")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel step program even with one rank (rehearsal of the collective path)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="all ranks on cuda:0 (gloo rehearsal of the multi-rank program on a one-GPU box)")
     ap.add_argument("--actor-bench", action="store_true", help="also time batched actor inference (untimed extra)")
     a = ap.parse_args()
 
+    if os.environ.get("PDA_BENCH_FAULTHANDLER"):     # debugging aid: dump every thread's stack if we stall
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PDA_BENCH_FAULTHANDLER"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and rank == 0:
         print("[bench] WORLD_SIZE=%d but --gpus %d: using WORLD_SIZE" % (world, a.gpus), file=sys.stderr)
-    device = torch.device("cuda:%d" % local)
+    device = torch.device("cuda:%d" % (0 if a.share_gpu else local))
     torch.cuda.set_device(device)
 
     from pytorch_distributed_amd.utils.options import Options
@@ -60,9 +68,9 @@ def main():
     from pytorch_distributed_amd.parallel.comm import comm_from_env
     from pytorch_distributed_amd.agents.learners import make_core
 
-    comm = comm_from_env(device)
+    comm = comm_from_env(device, backend=a.backend, force=a.force_dp)
     opt = prepare_options(Options(config=a.config, overrides={
-        "device": "cuda", "compute": a.compute, "num_learners": world,
+        "device": "cuda", "compute": a.compute, "num_learners": world, "force_dp": a.force_dp,
         "memory_params.memory_size": a.replay * world,      # each rank keeps a `replay`-sized shard
         "agent_params.batch_size": a.batch}))
     ap_ = opt.agent_params
@@ -117,6 +125,13 @@ def main():
     loss = core.loss_values().get("critic_loss", float("nan"))
 
     extra = {}
+    if world > 1:       # after the timed region: every rank must hold the same parameters
+        mine = core.flat_params().detach().clone()
+        ref = mine.clone()
+        comm.broadcast_(ref, src=0)
+        diff = (mine - ref).abs().max().reshape(1)
+        torch.distributed.all_reduce(diff, op=torch.distributed.ReduceOp.MAX)
+        extra["dp_param_max_abs_diff_across_ranks"] = float(diff.item())
     if a.actor_bench and rank == 0 and native:
         from pytorch_distributed_amd.ops.dqn_engine import DqnCnnInference
         for nact in (8, 256):
@@ -152,6 +167,9 @@ def main():
                        "replay_kind": "prioritized (HIP sum/min tree)" if memory.enable_per else "uniform",
                        "optimizer": "adam lr=%g" % ap_.lr, "target_update": ap_.target_model_update,
                        "parallelism": "dp%d" % world, "engine": type(core).__name__,
+                       "collectives": (getattr(comm, "backend", None) if getattr(getattr(core, "program", None), "dp", False)
+                                       else None),
+                       "dp_graph": getattr(getattr(core, "program", None), "dp_graph_mode", None),
                        "hip_graph": bool(native and not a.no_graph)},
         }
         out.update(extra)

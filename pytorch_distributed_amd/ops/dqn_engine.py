@@ -26,6 +26,7 @@ fp32 master weights live in the model's own flat buffer, so state_dict(),
 checkpoints and weight publishing see ordinary PyTorch parameters.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -364,6 +365,10 @@ class DqnCnnEngine(object):
     def update(self, staged=False, tick=False):
         """tick: bump Adam's step counter here (the head kernel does it in a full step)."""
         self.adam.step(tick=tick)
+        self.post_update(staged)
+
+    def post_update(self, staged=False):
+        """What follows the optimizer: soft target update, sum/min-tree repair of the sampled leaves."""
         if self.target_update < 1.0:
             polyak_(self.target.flat, self.online.flat, float(self.target_update), self.target.table,
                     self.target.shadow)
@@ -388,22 +393,33 @@ class DqnCnnEngine(object):
 class DqnStepProgram(object):
     """Sequences an engine's step and captures it into hipGraphs.
 
-    world_size == 1: one graph per step.  Data parallel: the step is cut where
-    the collectives go -- [sample, forward, head, fc wgrad] | all-reduce(fc tail)
-    on the comm stream, overlapped with [conv backward] | all-reduce(conv head)
-    | [adam, target, tree repair]."""
+    One rank: one graph per step.  Data parallel (one process per GPU, RCCL): the step is cut
+    where the collectives go, and both all-reduces run on a side stream under other work:
 
-    def __init__(self, engine, comm=None, use_graph=True, staged=False):
+      main   [A: sample, forward, head, fc wgrad] [B: conv backward ........] [Adam(fc tail)] [Adam(conv), target, tree]
+      comm                                 all-reduce(fc tail, 95 % of bytes)   all-reduce(conv grads)
+
+    The all-reduce is a SUM; the 1/world_size is Adam's grad_scale, so no scaling launch exists."""
+
+    def __init__(self, engine, comm=None, use_graph=True, staged=False, force_dp=False):
         self.e, self.comm, self.staged = engine, comm, staged
         self.world = comm.world_size if comm is not None else 1
+        self.dp = comm is not None and (self.world > 1 or force_dp)
         self.use_graph = use_graph
         self.graphs = None
+        self.dp_graph_mode = None
         self.calls = 0
-        if self.world > 1:
-            self.comm_stream = torch.cuda.Stream(device=engine.device)
-            self.fc_done = torch.cuda.Event()
-            self.tail = engine.grads[engine.tail_start:]
-            self.head = engine.grads[:engine.tail_start]
+        if self.dp:
+            e = engine
+            e.adam.set_grad_scale(1.0 / self.world)
+            self.comm_stream = torch.cuda.Stream(device=e.device)
+            self.fc_done, self.conv_done = torch.cuda.Event(), torch.cuda.Event()
+            self.tail_done, self.head_done = torch.cuda.Event(), torch.cuda.Event()
+            self.tail = e.grads[e.tail_start:]
+            self.head = e.grads[:e.tail_start]
+            first_tail_seg = 2 * e.online.ORDER.index("critic.1.0")     # (weight, bias) segment pairs per layer
+            self.tail_table = e.online.table.subset(lambda s: s >= first_tail_seg)
+            self.head_table = e.online.table.subset(lambda s: s < first_tail_seg)
 
     def _part_a(self):
         if not self.staged:
@@ -417,49 +433,86 @@ class DqnStepProgram(object):
     def _part_c(self):
         self.e.update(self.staged)
 
+    def _whole(self):
+        self._part_a()
+        self._part_b()
+        self._part_c()
+
     def _capture(self, fns):
         graphs = []
         for fn in fns:
             gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
+            # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                 fn()
             graphs.append(gr)
         return graphs
 
-    def _run_parts(self, parts):
-        if self.world == 1:
-            for p in parts:
-                p()
-            return
-        a, b, c = parts
-        cur = torch.cuda.current_stream()
+    def _run_dp(self, a, b):
+        """One data-parallel step on the current stream + the comm stream.  Works eagerly, with
+        a/b replaying captured graphs, and -- because every cross-stream edge is an event --
+        inside a stream capture, where the comm stream becomes a forked branch of ONE graph."""
+        e, cur = self.e, torch.cuda.current_stream()
         a()
         self.fc_done.record(cur)
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(self.fc_done)
-            self.comm.all_reduce_mean_(self.tail)
+            self.comm.all_reduce_sum_(self.tail)
+            self.tail_done.record(self.comm_stream)
         b()
-        self.comm.all_reduce_mean_(self.head)
-        cur.wait_stream(self.comm_stream)
-        c()
+        self.conv_done.record(cur)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(self.conv_done)
+            self.comm.all_reduce_sum_(self.head)
+            self.head_done.record(self.comm_stream)
+        cur.wait_event(self.tail_done)
+        e.adam.step(table=self.tail_table)          # fc tail update runs under the conv all-reduce
+        cur.wait_event(self.head_done)
+        e.adam.step(table=self.head_table)
+        e.post_update(self.staged)
+
+    def _dp_whole(self):
+        self._run_dp(self._part_a, self._part_b)
+
+    def _capture_dp(self):
+        """Preferred: the whole step, collectives included, as one graph (one host call per
+        step).  If the runtime refuses to capture the collectives, fall back to two compute
+        graphs with eagerly launched collectives between them."""
+        mode = os.environ.get("PDA_DP_GRAPH", "whole")
+        if mode == "whole":
+            try:
+                graphs = self._capture([self._dp_whole])
+                self.dp_graph_mode = "whole"
+                return graphs
+            except Exception as exc:       # pragma: no cover - depends on the RCCL build
+                print("[dqn_engine] whole-step capture with collectives failed (%s); "
+                      "falling back to split graphs" % (exc,), flush=True)
+                torch.cuda.synchronize()
+        self.dp_graph_mode = "split"
+        return self._capture([self._part_a, self._part_b])
 
     def step(self):
         e = self.e
-        eager = [self._part_a, self._part_b, self._part_c]
-        if not self.use_graph or self.calls == 0:
-            # the first step runs eagerly: it loads every code object, so nothing is
-            # lazily initialised while a stream is capturing
-            self._run_parts(eager)
-        else:
-            if self.graphs is None:
-                if self.world == 1:
-                    self.graphs = self._capture([lambda: (self._part_a(), self._part_b(), self._part_c())])
-                else:
-                    self.graphs = self._capture(eager)
-            if self.world == 1:
-                self.graphs[0].replay()
+        first = (not self.use_graph) or self.calls == 0
+        # the first step runs eagerly: it loads every code object (and lets RCCL set up its
+        # channels), so nothing is lazily initialised while a stream is capturing
+        if not self.dp:
+            if first:
+                self._whole()
             else:
-                self._run_parts([g.replay for g in self.graphs])
+                if self.graphs is None:
+                    self.graphs = self._capture([self._whole])
+                self.graphs[0].replay()
+        else:
+            if first:
+                self._dp_whole()
+            else:
+                if self.graphs is None:
+                    self.graphs = self._capture_dp()
+                if len(self.graphs) == 1:
+                    self.graphs[0].replay()
+                else:
+                    self._run_dp(self.graphs[0].replay, self.graphs[1].replay)
         self.calls += 1
         e.loss_steps += 1
         if e.target_update >= 1.0 and e.step_count % int(e.target_update) == 0:
@@ -470,7 +523,7 @@ class DqnStepProgram(object):
 class DqnNativeCore(object):
     """Learner-loop adapter (agents/learners.py): same surface as DqnTorchCore."""
 
-    def __init__(self, args, model, target_model, memory, comm=None, use_graph=True):
+    def __init__(self, args, model, target_model, memory, comm=None, use_graph=True, force_dp=False):
         ap, mp_ = args.agent_params, args.memory_params
         self.args, self.ap, self.memory, self.comm = args, ap, memory, comm
         self.model, self.target_model = model, target_model
@@ -488,7 +541,8 @@ class DqnNativeCore(object):
             self.engine.bind_replay(memory.state0s, memory.state1s, memory.tails, memory.tree)
         else:
             self.engine.make_staging(a + 3 * k + 1)
-        self.program = DqnStepProgram(self.engine, comm, use_graph=use_graph, staged=not self.on_device)
+        self.program = DqnStepProgram(self.engine, comm, use_graph=use_graph, staged=not self.on_device,
+                                      force_dp=force_dp or bool(getattr(args, "force_dp", False)))
         self._last_size = -1
         self.step_count = 0
 

@@ -448,12 +448,15 @@ class MlpStepProgram(object):
     """[sample, stage, forward, head, backward] | all-reduce(flat grads) | [adam, target, tree repair];
     one hipGraph per bracket (a single graph when there is one rank)."""
 
-    def __init__(self, engine, comm=None, use_graph=True, staged=False):
+    def __init__(self, engine, comm=None, use_graph=True, staged=False, force_dp=False):
         self.e, self.comm, self.staged = engine, comm, staged
         self.world = comm.world_size if comm is not None else 1
+        self.dp = comm is not None and (self.world > 1 or force_dp)
         self.use_graph = use_graph
         self.graphs = None
         self.calls = 0
+        if self.dp:     # the all-reduce is a SUM; Adam applies the 1/world_size
+            engine.adam.set_grad_scale(1.0 / self.world)
 
     def _part_a(self):
         if not self.staged:
@@ -472,7 +475,7 @@ class MlpStepProgram(object):
         graphs = []
         for fn in fns:
             gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                 fn()
             graphs.append(gr)
         return graphs
@@ -480,20 +483,20 @@ class MlpStepProgram(object):
     def step(self):
         e = self.e
         if not self.use_graph or self.calls == 0:
-            if self.world == 1:
+            if not self.dp:
                 self._all()
             else:
                 self._part_a()
-                self.comm.all_reduce_mean_(e.grads)
+                self.comm.all_reduce_sum_(e.grads)
                 self._part_c()
         else:
             if self.graphs is None:
-                self.graphs = self._capture([self._all] if self.world == 1 else [self._part_a, self._part_c])
-            if self.world == 1:
+                self.graphs = self._capture([self._part_a, self._part_c] if self.dp else [self._all])
+            if not self.dp:
                 self.graphs[0].replay()
             else:
                 self.graphs[0].replay()
-                self.comm.all_reduce_mean_(e.grads)
+                self.comm.all_reduce_sum_(e.grads)
                 self.graphs[1].replay()
         self.calls += 1
         e.loss_steps += 1
@@ -530,7 +533,8 @@ class MlpNativeCore(object):
             self.engine.bind_replay(memory.state0s, memory.state1s, memory.tails, memory.tree)
         else:
             self.engine.make_staging(a + 3 * k + 1)
-        self.program = MlpStepProgram(self.engine, comm, use_graph=use_graph, staged=not self.on_device)
+        self.program = MlpStepProgram(self.engine, comm, use_graph=use_graph, staged=not self.on_device,
+                                      force_dp=bool(getattr(args, "force_dp", False)))
         self._last_size = -1
         self.step_count = 0
 

@@ -42,6 +42,18 @@ class SegmentTable(object):
         self.segs = torch.tensor(rows, dtype=torch.int32).to(device)
         self.chunks = torch.tensor(chunks, dtype=torch.int32).to(device)
         self.nchunks = len(chunks)
+        self._chunk_list = chunks
+
+    def subset(self, keep):
+        """A view of this table restricted to the segments for which keep(segment_index) is true
+        (same segment rows, fewer chunks)."""
+        sub = object.__new__(SegmentTable)
+        sub.segs = self.segs
+        chunks = [c for c in self._chunk_list if keep(c[0])]
+        sub._chunk_list = chunks
+        sub.chunks = torch.tensor(chunks if chunks else [[0, 0]], dtype=torch.int32).to(self.segs.device)
+        sub.nchunks = len(chunks)
+        return sub
 
 
 def plain_table(numel, device):
@@ -68,13 +80,22 @@ class FlatAdam(object):
     def set_lr(self, lr):
         self.hyper[0] = float(lr)
 
-    def step(self, tick=False):
+    def step(self, tick=False, table=None):
         """tick=True bumps the step counter with an extra tiny launch; engines whose
-        loss kernel already bumps it (dqn_head / td_vector) pass False."""
+        loss kernel already bumps it (dqn_head / td_vector) pass False.  `table` restricts the
+        launch to a subset of the segments (SegmentTable.subset) -- the DP step updates the fc
+        tail while the conv gradients are still being all-reduced."""
         if tick:
             lib().pda_tick(_p(self.step_dev), _vp(0), _stream())
-        lib().pda_adam(_p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.shadow), _p(self.table.segs),
-                       _p(self.table.chunks), self.table.nchunks, _p(self.hyper), _p(self.step_dev), _stream())
+        t = table if table is not None else self.table
+        if t.nchunks == 0:
+            return
+        lib().pda_adam(_p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.shadow), _p(t.segs),
+                       _p(t.chunks), t.nchunks, _p(self.hyper), _p(self.step_dev), _stream())
+
+    def set_grad_scale(self, scale):
+        """Gradients are multiplied by this before clipping (1/world_size after a SUM all-reduce)."""
+        self.hyper[6] = float(scale)
 
 
 def polyak_(tgt_flat, src_flat, tau, table=None, shadow=None):

@@ -177,10 +177,14 @@ def make_comm(rank, world_size, device, port=None, backend=None):
     return TorchComm(rank, world_size, device, init_method="tcp://127.0.0.1:%d" % port, backend=backend)
 
 
-def comm_from_env(device):
-    """Build a communicator from torchrun's RANK/WORLD_SIZE/MASTER_* env."""
+def comm_from_env(device, backend=None, force=False):
+    """Build a communicator from torchrun's RANK/WORLD_SIZE/MASTER_* env.  `force` builds a real
+    process group even for one rank (rehearses the RCCL path on a single GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world <= 1:
+    if world <= 1 and not force:
         return SingleComm()
-    return TorchComm(rank, world, device)
+    init = None
+    if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:
+        init = "tcp://127.0.0.1:%d" % int(os.environ.get("PDA_DIST_PORT", "29533"))
+    return TorchComm(rank, max(world, 1), device, init_method=init, backend=backend)

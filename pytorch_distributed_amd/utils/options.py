@@ -115,6 +115,7 @@ class Params(object):
         self.supervise = True               # restart dead actors, stop everything if a learner dies
         self.inject_fault = None            # e.g. "actor:1@50" kills actor 1 at its 50th step (tests)
         self.ingest = "ring"                # "ring": lock-free shm ring into device replay | "direct"
+        self.force_dp = False               # run the data-parallel step program even with one learner (rehearsal)
 
         # prefix for saving models&logs
         self.root_dir = overrides.get("root_dir", os.getcwd())
