@@ -59,6 +59,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and rank == 0:
         print("[bench] WORLD_SIZE=%d but --gpus %d: using WORLD_SIZE" % (world, a.gpus), file=sys.stderr)
+    if (world > 1 or a.force_dp) and (a.backend in (None, "nccl")) and a.compute == "native":
+        # ask a throw-away child whether this node captures RCCL collectives into a hipGraph
+        # (must happen before this process initialises the GPU); sets the DP step's graph mode
+        from pytorch_distributed_amd.parallel.preflight import choose_dp_graph_mode
+        os.environ["PDA_DP_GRAPH"] = choose_dp_graph_mode()
     device = torch.device("cuda:%d" % (0 if a.share_gpu else local))
     torch.cuda.set_device(device)
 
