@@ -53,6 +53,7 @@ def evaluator(process_ind, args, global_logs, evaluator_logs, env_prototype, mod
     sync_params(local_model, global_model)
     local_model.eval()
     torch.set_grad_enabled(False)
+    torch.set_num_threads(max(1, min(2, torch.get_num_threads())))     # the env workers need the cores
     poll = float(getattr(ap, "poll_interval", 5.0))
 
     def evaluate_and_save():

@@ -148,6 +148,18 @@ def make_core(kind, args, model, target_model, memory, comm, device):
     return (DqnTorchCore if kind == "dqn" else DdpgTorchCore)(args, model, target_model, memory, comm)
 
 
+def _host_inference(args, core, model, mailbox, device):
+    engine = getattr(core, "engine", None)
+    if device.type != "cuda" or engine is None or not hasattr(engine, "online"):
+        raise RuntimeError("inference_placement='learner' needs the native HIP learner core on a GPU")
+    from ..ops.infer import make_native_server
+    server = make_native_server(args, model, mailbox, device, high_priority=True, weights=engine.online)
+    if server is None:
+        raise RuntimeError("no native inference program for model_type %r" % args.model_type)
+    server.start()
+    return server
+
+
 def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
                   global_memory, global_model, global_optimizer, kind):
     print("---------------------------->", process_ind, "learner")
@@ -180,6 +192,14 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
     torch.set_grad_enabled(True)
     core = make_core(kind, args, local_model, local_target_model, global_memory, comm, local_device)
 
+    # batched actor inference hosted here: a native loop thread on a high-priority stream that
+    # reads this learner's live bf16 shadow weights (no weight hand-off for the actors at all)
+    hosted = None
+    if rank == 0 and args.actor_inference == "batched" and getattr(global_model, "mailbox", None) is not None:
+        from ..parallel.inference_server import resolve_placement
+        if resolve_placement(args) == "learner":
+            hosted = _host_inference(args, core, local_model, global_model.mailbox, local_device)
+
     step = 0
     started = False
     while step < ap.steps and not global_logs.stop.value:
@@ -205,6 +225,13 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
                 global_logs.beat("learner")
     if rank == 0:
         publish_params(global_model, core.flat_params())
+    if hosted is not None:
+        hosted.stop()
+        global_model.mailbox.closed[0] = 1
+        st = hosted.stats()
+        print("[inference@learner] %d requests in %d batches (mean %.1f per batch, %.0f us per batch)"
+              % (st["requests"], st["batches"], st["mean_batch"], st["mean_batch_us"]), flush=True)
+        hosted.close()
     comm.close()
 
 

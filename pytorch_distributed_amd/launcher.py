@@ -17,6 +17,7 @@ import torch
 import torch.multiprocessing as mp
 
 from .utils.checkpoint import load_state_dict
+from .parallel.inference_server import resolve_placement
 from .utils.param_store import share_model
 
 
@@ -153,7 +154,7 @@ def run(opt):
     ind = opt.num_actors + opt.num_learners + 1
     sup.start("evaluator", ind, EvaluatorsDict[opt.agent_type],
               (ind, opt, global_logs, evaluator_logs, env_prototype, model_prototype, global_model))
-    if opt.actor_inference == "batched":
+    if opt.actor_inference == "batched" and resolve_placement(opt) == "process":
         from .parallel.inference_server import inference_server
         sup.start("inference", ind + 2, inference_server,
                   (ind + 2, opt, global_logs, model_prototype, global_model))

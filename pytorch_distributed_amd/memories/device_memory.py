@@ -84,13 +84,22 @@ class DeviceMemory(Memory):
         self.gamma1s = self.tails[:, a + k:a + 2 * k]
         self.terminal1s = self.tails[:, a + 2 * k:a + 3 * k]
         self.init_priorities = self.tails[:, a + 3 * k]
-        self.staging = torch.zeros(self.ingest_chunk, c.record_bytes, dtype=torch.uint8)
-        if dev.type == "cuda":
-            self.staging = self.staging.pin_memory()
-            self.staging_dev = torch.zeros_like(self.staging, device=dev)
-            self.copy_stream = torch.cuda.Stream(device=dev)
-        else:
-            self.staging_dev = self.staging
+        # ingestion staging: a small ring of pinned host buffers, each with its device twin and an
+        # event, so drain() never waits for the GPU (a buffer is reused only once its copy landed)
+        nbuf = 4 if dev.type == "cuda" else 1
+        self.staging, self.staging_dev, self.staging_evt = [], [], []
+        for _ in range(nbuf):
+            host = torch.zeros(self.ingest_chunk, c.record_bytes, dtype=torch.uint8)
+            if dev.type == "cuda":
+                host = host.pin_memory()
+                self.staging_dev.append(torch.zeros_like(host, device=dev))
+                self.staging_evt.append(None)
+            else:
+                self.staging_dev.append(host)
+                self.staging_evt.append(None)
+            self.staging.append(host)
+        self._stage_next = 0
+        self._pos_base = torch.arange(self.ingest_chunk, device=dev, dtype=torch.int64)
         self.tree = DeviceSumMinTree(m, dev) if self.enable_per else None
         self._gen = torch.Generator(device=dev)
         self._gen.manual_seed(1234 + rank)
@@ -104,8 +113,8 @@ class DeviceMemory(Memory):
     def ingest_records(self, records_dev, n):
         """Scatter n packed records (already on the replay device) into the ring."""
         m = self.memory_size
-        positions = (torch.arange(n, device=self.device, dtype=torch.int64) + self.pos) % m
-        positions = positions.to(torch.int32)
+        base = self._pos_base[:n] if n <= self._pos_base.numel() else torch.arange(n, device=self.device)
+        positions = ((base + self.pos) % m).to(torch.int32)
         c = self.codec
         replay_ops.unpack_records(records_dev, n, positions, self.state0s, self.state1s, self.tails,
                                   c.state_bytes, c.state_stride, c.tail_floats)
@@ -120,18 +129,27 @@ class DeviceMemory(Memory):
             self.shared_size.value = self.size
 
     def drain(self, max_chunks=4):
-        """Move up to max_chunks*ingest_chunk transitions ring -> HBM.  Returns count."""
+        """Move up to max_chunks*ingest_chunk transitions ring -> HBM.  Returns count.
+        Never blocks on the GPU: the pop lands in a pinned buffer whose previous H2D copy has
+        completed (event query), the copy and the unpack kernel are enqueued on the current
+        stream behind whatever the learner already queued there."""
         moved = 0
+        cuda = self.device.type == "cuda"
         for _ in range(max_chunks):
-            n = self.ring.pop_many(self.staging, self.ingest_chunk)
+            i = self._stage_next
+            evt = self.staging_evt[i]
+            if evt is not None and not evt.query():
+                break                       # every staging buffer still in flight: try again next step
+            n = self.ring.pop_many(self.staging[i], self.ingest_chunk)
             if n == 0:
                 break
-            if self.device.type == "cuda":
-                # the staging buffer is reused next iteration: copy on the current
-                # stream (ordered before the unpack kernel), pinned -> async DMA
-                self.staging_dev[:n].copy_(self.staging[:n], non_blocking=True)
-                torch.cuda.current_stream(self.device).synchronize()
-            self.ingest_records(self.staging_dev, n)
+            if cuda:
+                self.staging_dev[i][:n].copy_(self.staging[i][:n], non_blocking=True)
+                if evt is None:
+                    evt = self.staging_evt[i] = torch.cuda.Event()
+                evt.record()
+            self.ingest_records(self.staging_dev[i], n)
+            self._stage_next = (i + 1) % len(self.staging)
             moved += n
             if n < self.ingest_chunk:
                 break

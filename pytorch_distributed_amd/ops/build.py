@@ -39,6 +39,7 @@ def build(force=False, verbose=False, extra_flags=()):
     os.makedirs(OBJ_DIR, exist_ok=True)
     sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     headers = sorted(glob.glob(os.path.join(CSRC, "*.h")))
+    headers += sorted(glob.glob(os.path.join(HERE, "..", "parallel", "csrc", "*.h")))   # mailbox protocol
     hipcc = _hipcc()
     jobs = []
     objs = []
@@ -61,7 +62,7 @@ def build(force=False, verbose=False, extra_flags=()):
         list(pool.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         tmp = LIB + ".tmp%d" % os.getpid()
-        run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp] + objs)
+        run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp] + objs + ["-lpthread"])
         os.replace(tmp, LIB)
     return LIB
 

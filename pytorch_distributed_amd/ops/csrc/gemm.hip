@@ -3,6 +3,7 @@
 // work -- no allocation, no synchronisation -- so callers can capture whole
 // learner steps into a hipGraph.
 #include "gemm.h"
+#include "api.h"
 
 namespace {
 

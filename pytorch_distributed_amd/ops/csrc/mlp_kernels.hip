@@ -3,7 +3,7 @@
 // (critic output layer + n-step TD target + both losses + the gradients that
 // start the two backward passes).  The dense layers themselves run on the MFMA
 // GEMM family in gemm.hip.
-#include "common.h"
+#include "api.h"
 
 // ----------------------------------------------------------------------------
 // staging: up to 6 jobs in one launch.  Job j copies `ncols` fp32 columns
@@ -12,8 +12,7 @@
 // row(b) = idx[b] (HBM replay, sampled indices) or b (host batch already staged).
 // Pad columns of dst are never written (they stay zero from allocation).
 // ----------------------------------------------------------------------------
-struct StageJob { const float* src; long ld_src; int src_col; int ncols; bf16_t* dst; long ld_dst; int dst_row0; float scale; };
-struct StageJobs { StageJob j[6]; };
+// (StageJob / StageJobs live in api.h)
 
 __global__ __launch_bounds__(256) void mlp_stage_kernel(StageJobs jobs, int njobs, const int* __restrict__ idx, int B) {
     const StageJob J = jobs.j[blockIdx.y];

@@ -1,7 +1,7 @@
 // RL-specific fused kernels: DQN head (fc2 + n-step TD target + loss + dQ +
 // priorities), critic TD for DDPG, fused Adam / Polyak over flat buffers with
 // bf16 shadow-weight emission, epsilon-greedy actor epilogue.
-#include "common.h"
+#include "api.h"
 
 // ----------------------------------------------------------------------------
 // DQN head.  One wave64 per sample; the 512-wide hidden row is 8 values per lane.
@@ -114,11 +114,7 @@ PDA_EXPORT void pda_dqn_head(const DqnHeadArgs* args, hipStream_t stream) {
 }
 
 // forward-only head for the actor server: q = W5 relu(h1pre + b4) + b5, then epsilon-greedy
-struct ActHeadArgs {
-    float* h1pre; const float* b4; const float* w5; const float* b5;
-    const float* eps; float* out; int out_ld;        // out[b] = {action, q[action], max q}
-    float* q_out; int B, HID, A; unsigned long long seed; const unsigned long long* counter;
-};
+// (ActHeadArgs lives in api.h: the native inference loop fills it too)
 
 template <int HID>
 __global__ __launch_bounds__(256) void act_head_kernel(ActHeadArgs p) {

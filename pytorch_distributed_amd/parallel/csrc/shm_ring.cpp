@@ -19,6 +19,8 @@
 #include <cstring>
 #include <new>
 
+#include "mailbox.h"
+
 namespace {
 
 constexpr uint64_t kMagic = 0x50444152494e4731ull;  // "PDARING1"
@@ -180,6 +182,27 @@ uint64_t pda_atomic_wait_ge(void* p, uint64_t target, uint64_t spins) {
         v = a->load(std::memory_order_acquire);
     }
     return v;
+}
+
+// ---- inference mailbox (protocol in mailbox.h) ------------------------------------------
+// Actor: copy the observation into its slot, post request number `k`, wait for the answer.
+// Returns the last resp value seen (>= k once answered); on a smaller value the caller checks
+// for shutdown and calls pda_mailbox_wait again.
+uint64_t pda_mailbox_request(void* seq_base, int slot, uint64_t k, void* obs_dst, const void* obs_src,
+                             uint64_t obs_bytes, uint32_t spins, uint32_t timeout_us) {
+    if (obs_bytes) std::memcpy(obs_dst, obs_src, obs_bytes);
+    pda_mailbox::req_word(seq_base, slot)->store(k, std::memory_order_release);
+    return pda_mailbox::wait_response(seq_base, slot, k, spins, timeout_us);
+}
+uint64_t pda_mailbox_wait(void* seq_base, int slot, uint64_t k, uint32_t spins, uint32_t timeout_us) {
+    return pda_mailbox::wait_response(seq_base, slot, k, spins, timeout_us);
+}
+// Server (host fallback; the GPU server runs the same protocol natively in libpda_hip.so)
+int pda_mailbox_collect(void* seq_base, int nslots, int* ids, uint64_t* req_seen, int max_out) {
+    return pda_mailbox::collect_pending(seq_base, nslots, ids, req_seen, max_out);
+}
+void pda_mailbox_post(void* seq_base, const int* ids, const uint64_t* req_seen, int n) {
+    for (int i = 0; i < n; ++i) pda_mailbox::post_response(seq_base, ids[i], req_seen[i]);
 }
 
 }  // extern "C"

@@ -9,13 +9,14 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "shm_ring.cpp")
+HEADERS = [os.path.join(_HERE, "csrc", "mailbox.h")]
 LIB_PATH = os.path.join(_HERE, "libpda_host.so")
 _LIB = None
 
 
 def build(force=False, sanitize=None):
     out = LIB_PATH if sanitize is None else LIB_PATH.replace(".so", "_%s.so" % sanitize)
-    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(SRC):
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(f) for f in [SRC] + HEADERS):
         return out
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", out + ".tmp%d" % os.getpid(), SRC]
     if sanitize:
@@ -51,5 +52,13 @@ def lib():
         L.pda_atomic_add.argtypes = [vp, u64]
         L.pda_atomic_wait_ge.restype = u64
         L.pda_atomic_wait_ge.argtypes = [vp, u64, u64]
+        L.pda_mailbox_request.restype = u64
+        L.pda_mailbox_request.argtypes = [vp, i32, u64, vp, vp, u64, u32, u32]
+        L.pda_mailbox_wait.restype = u64
+        L.pda_mailbox_wait.argtypes = [vp, i32, u64, u32, u32]
+        L.pda_mailbox_collect.restype = i32
+        L.pda_mailbox_collect.argtypes = [vp, i32, vp, vp, i32]
+        L.pda_mailbox_post.restype = None
+        L.pda_mailbox_post.argtypes = [vp, vp, vp, i32]
         _LIB = L
     return _LIB

@@ -35,6 +35,7 @@ class InferenceMailbox(object):
         self.action_shape = int(action_shape)
         self._np = None
         self._count = {}
+        self._ids = None
 
     def _views(self):
         if self._np is None:
@@ -45,6 +46,7 @@ class InferenceMailbox(object):
         d = self.__dict__.copy()
         d["_np"] = None
         d["_count"] = {}
+        d["_ids"] = None
         return d
 
     def set_epsilon(self, slot, eps):
@@ -58,27 +60,30 @@ class InferenceMailbox(object):
 
     # ---- actor side --------------------------------------------------------
     def request(self, slot, state, timeout_s=120.0):
+        """Post one observation and block until the server answers: one C call that copies the
+        observation into the slot, release-stores the request number, spins briefly and then
+        sleeps on a futex (parallel/csrc/mailbox.h) -- the GIL is released throughout."""
         L = hostlib.lib()
-        obs, out, _ = self._views()
-        obs[slot] = state
+        obs, out, seq = self._views()
+        src = np.ascontiguousarray(state, dtype=obs.dtype).reshape(-1)
         k = self._count.get(slot)
         if k is None:
             k = int(L.pda_atomic_load(self._req_ptr(slot)))
         k += 1
         self._count[slot] = k
-        L.pda_atomic_store(self._req_ptr(slot), k)
-        deadline = time.time() + timeout_s
-        delay = 2e-5
-        while True:
-            if L.pda_atomic_wait_ge(self._resp_ptr(slot), k, 2000) >= k:
-                break
+        row = obs[slot]
+        got = L.pda_mailbox_request(seq, slot, k, row.ctypes.data, src.ctypes.data, src.nbytes, 4000, 2000)
+        deadline = None
+        while got < k:
             if int(self.closed[0]) != 0:      # job is shutting down: hand back a no-op action
                 a = self.action_shape
                 return (np.zeros((1, 1), dtype=np.int64) if self.discrete else np.zeros((1, a))), 0.0, 0.0
-            if time.time() > deadline:
+            now = time.time()
+            if deadline is None:
+                deadline = now + timeout_s
+            elif now > deadline:
                 raise TimeoutError("inference server did not answer slot %d" % slot)
-            time.sleep(delay)
-            delay = min(delay * 1.5, 1e-3)
+            got = L.pda_mailbox_wait(seq, slot, k, 0, 2000)
         a = self.action_shape
         row = out[slot]
         if self.discrete:
@@ -87,22 +92,26 @@ class InferenceMailbox(object):
             action = row[:a].astype(np.float64).reshape(1, a)
         return action, float(row[a]), float(row[a + 1])
 
-    # ---- server side -------------------------------------------------------------
+    # ---- server side (host fallback; the GPU path is ops/infer.py) -----------------------
     def pending(self):
-        seq = self.seq.numpy()
-        req, resp = seq[:, 0].copy(), seq[:, 8]
-        ids = np.nonzero(req > resp)[0]
-        return ids, req[ids]
+        L = hostlib.lib()
+        if self._ids is None:
+            self._ids = np.zeros(self.num_slots, dtype=np.int32)
+            self._reqs = np.zeros(self.num_slots, dtype=np.uint64)
+        n = L.pda_mailbox_collect(self._views()[2], self.num_slots, self._ids.ctypes.data,
+                                  self._reqs.ctypes.data, self.num_slots)
+        return self._ids[:n].copy(), self._reqs[:n].copy()
 
     def respond(self, ids, req_seen, actions, qvalues, max_qvalues):
         L = hostlib.lib()
-        _, out, _ = self._views()
+        _, out, seq = self._views()
         a = self.action_shape
         out[ids, :a] = np.asarray(actions, dtype=np.float32).reshape(len(ids), a)
         out[ids, a] = qvalues
         out[ids, a + 1] = max_qvalues
-        for i, k in zip(ids, req_seen):
-            L.pda_atomic_store(self._resp_ptr(int(i)), int(k))
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        req_seen = np.ascontiguousarray(req_seen, dtype=np.uint64)
+        L.pda_mailbox_post(seq, ids.ctypes.data, req_seen.ctypes.data, len(ids))
 
 
 class BatchedPolicy(object):
@@ -152,6 +161,25 @@ class BatchedPolicy(object):
         return act.float().cpu().numpy(), z, z
 
 
+def resolve_placement(args):
+    """Where the batched policy runs: "learner" = a native loop thread inside learner rank 0 (shares
+    the learner's live weights, high-priority stream), "process" = a process of its own."""
+    place = getattr(args, "inference_placement", "auto")
+    if place != "auto":
+        return place
+    return "process"
+
+
+def _native_server(args, model, mailbox, device):
+    if device.type != "cuda" or getattr(args, "compute", "auto") == "torch":
+        return None
+    from .. import ops
+    if not ops.native_available():
+        return None
+    from ..ops.infer import make_native_server
+    return make_native_server(args, model, mailbox, device)
+
+
 def inference_server(process_ind, args, global_logs, model_prototype, global_model):
     print("---------------------------->", process_ind, "inference server")
     mailbox = global_model.mailbox
@@ -163,12 +191,34 @@ def inference_server(process_ind, args, global_logs, model_prototype, global_mod
     version = sync_params(model, global_model)
     model.eval()
     torch.set_grad_enabled(False)
-    policy = BatchedPolicy(args, model, device)
-    policy.refresh()
     try:
-        _serve(args, global_logs, global_model, mailbox, model, policy, device, version)
+        native = _native_server(args, model, mailbox, device)
+        if native is not None:
+            _serve_native(args, global_logs, global_model, native, version)
+        else:
+            policy = BatchedPolicy(args, model, device)
+            policy.refresh()
+            _serve(args, global_logs, global_model, mailbox, model, policy, device, version)
     finally:
         mailbox.closed[0] = 1
+
+
+def _serve_native(args, global_logs, global_model, native, version, poll_s=0.02):
+    """The C++ loop thread answers the actors; this thread only re-syncs the weights."""
+    native.start()
+    try:
+        while global_logs.running(args.agent_params.steps):
+            time.sleep(poll_s)
+            v = global_model.param_version.value
+            if v != version and v % 2 == 0:
+                version = native.refresh_from(global_model)
+    finally:
+        native.stop()
+        st = native.stats()
+        print("[inference] %d requests in %d batches (mean %.1f / max %d per batch, %.0f us per batch, "
+              "zero-copy mailbox: %s)" % (st["requests"], st["batches"], st["mean_batch"], st["max_batch"],
+                                          st["mean_batch_us"], bool(st["registered"])), flush=True)
+        native.close()
 
 
 def _serve(args, global_logs, global_model, mailbox, model, policy, device, version):
