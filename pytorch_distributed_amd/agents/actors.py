@@ -64,6 +64,12 @@ def _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model
         local_model.eval()
     torch.set_grad_enabled(False)
     torch.set_num_threads(1)
+    nice = int(getattr(args, "actor_nice", 0))
+    if nice > 0:        # env workers yield the cores to the learner / inference threads when oversubscribed
+        try:
+            os.nice(nice)
+        except OSError:
+            pass
 
     enable_per = bool(mp_.enable_per) and kind == "dqn"
     if kind == "dqn":

@@ -225,6 +225,8 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
                 global_logs.beat("learner")
     if rank == 0:
         publish_params(global_model, core.flat_params())
+    if hasattr(global_memory, "close"):
+        global_memory.close()
     if hosted is not None:
         hosted.stop()
         global_model.mailbox.closed[0] = 1

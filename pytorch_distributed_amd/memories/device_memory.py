@@ -99,6 +99,19 @@ class DeviceMemory(Memory):
                 self.staging_evt.append(None)
             self.staging.append(host)
         self._stage_next = 0
+        # GPU replay: a native pump thread fills the pinned buffers (parallel/csrc/shm_ring.cpp), the
+        # learner thread only enqueues DMAs.  Host replay keeps the simple in-line pop.
+        self.pump = None
+        self._in_flight = []        # [(buffer index, event)] DMAs not yet known complete
+        if dev.type == "cuda" and getattr(self, "use_pump", True):
+            import ctypes
+            from ..parallel import hostlib
+            L = hostlib.lib()
+            ptrs = (ctypes.c_void_p * nbuf)(*[t.data_ptr() for t in self.staging])
+            self.pump = L.pda_pump_create(self.ring.base, nbuf, ptrs, self.ingest_chunk, c.record_bytes, 300)
+            if not self.pump:
+                raise RuntimeError("ingestion pump could not attach to the ring")
+            self._pump_n = ctypes.c_int(0)
         self._pos_base = torch.arange(self.ingest_chunk, device=dev, dtype=torch.int64)
         self.tree = DeviceSumMinTree(m, dev) if self.enable_per else None
         self._gen = torch.Generator(device=dev)
@@ -133,6 +146,8 @@ class DeviceMemory(Memory):
         Never blocks on the GPU: the pop lands in a pinned buffer whose previous H2D copy has
         completed (event query), the copy and the unpack kernel are enqueued on the current
         stream behind whatever the learner already queued there."""
+        if self.pump is not None:
+            return self._drain_pumped(max_chunks)
         moved = 0
         cuda = self.device.type == "cuda"
         for _ in range(max_chunks):
@@ -154,6 +169,34 @@ class DeviceMemory(Memory):
             if n < self.ingest_chunk:
                 break
         return moved
+
+    def _drain_pumped(self, max_chunks):
+        import ctypes
+        from ..parallel import hostlib
+        L = hostlib.lib()
+        while self._in_flight and self._in_flight[0][1].query():        # give finished buffers back
+            L.pda_pump_release(self.pump, self._in_flight.pop(0)[0])
+        moved = 0
+        for _ in range(max_chunks):
+            i = L.pda_pump_take(self.pump, ctypes.byref(self._pump_n))
+            if i < 0:
+                break
+            n = self._pump_n.value
+            self.staging_dev[i][:n].copy_(self.staging[i][:n], non_blocking=True)
+            evt = self.staging_evt[i]
+            if evt is None:
+                evt = self.staging_evt[i] = torch.cuda.Event()
+            evt.record()
+            self._in_flight.append((i, evt))
+            self.ingest_records(self.staging_dev[i], n)
+            moved += n
+        return moved
+
+    def close(self):
+        if getattr(self, "pump", None):
+            from ..parallel import hostlib
+            hostlib.lib().pda_pump_destroy(self.pump)
+            self.pump = None
 
     def feed_batch(self, state0s, actions, rewards, gamma1s, state1s, terminal1s, priorities=None):
         """Direct device-side ingestion of n transitions already on the replay

@@ -18,7 +18,7 @@ def build(force=False, sanitize=None):
     out = LIB_PATH if sanitize is None else LIB_PATH.replace(".so", "_%s.so" % sanitize)
     if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(f) for f in [SRC] + HEADERS):
         return out
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", out + ".tmp%d" % os.getpid(), SRC]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-o", out + ".tmp%d" % os.getpid(), SRC]
     if sanitize:
         cmd[1:1] = ["-fsanitize=%s" % sanitize, "-g"]
     subprocess.check_call(cmd)
@@ -52,6 +52,16 @@ def lib():
         L.pda_atomic_add.argtypes = [vp, u64]
         L.pda_atomic_wait_ge.restype = u64
         L.pda_atomic_wait_ge.argtypes = [vp, u64, u64]
+        L.pda_pump_create.restype = vp
+        L.pda_pump_create.argtypes = [vp, i32, vp, u32, u32, u32]
+        L.pda_pump_take.restype = i32
+        L.pda_pump_take.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
+        L.pda_pump_release.restype = None
+        L.pda_pump_release.argtypes = [vp, i32]
+        L.pda_pump_moved.restype = u64
+        L.pda_pump_moved.argtypes = [vp]
+        L.pda_pump_destroy.restype = None
+        L.pda_pump_destroy.argtypes = [vp]
         L.pda_mailbox_request.restype = u64
         L.pda_mailbox_request.argtypes = [vp, i32, u64, vp, vp, u64, u32, u32]
         L.pda_mailbox_wait.restype = u64

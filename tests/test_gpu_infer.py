@@ -150,3 +150,40 @@ def test_ddpg_actor_program(native):
         np.testing.assert_allclose(mailbox.out[s, :A].numpy(), ref[s], atol=0.03)
         assert float(mailbox.out[s, A]) == 0.0 and float(mailbox.out[s, A + 1]) == 0.0
     server.close()
+
+
+def test_pumped_ingestion_into_hbm_replay(native):
+    """actors' feed() -> shm ring -> native pump thread -> pinned staging -> async H2D -> unpack kernel."""
+    import time
+    from pytorch_distributed_amd.launcher import prepare_options
+    from pytorch_distributed_amd.memories.device_memory import DeviceMemory
+    from pytorch_distributed_amd.utils.options import Options
+    opt = prepare_options(Options(config=4, overrides={"memory_params.memory_size": 1024,
+                                                       "memory_params.ingest_chunk": 64,
+                                                       "memory_params.ingest_ring_slots": 256}))
+    mem = DeviceMemory(opt.memory_params)
+    rng = np.random.RandomState(5)
+    n = 300
+    s0 = rng.randint(0, 256, size=(n, 4, 84, 84)).astype(np.uint8)
+    s1 = rng.randint(0, 256, size=(n, 4, 84, 84)).astype(np.uint8)
+    mem.attach(torch.device("cuda:0"))
+    assert mem.pump is not None
+    fed = 0
+    moved = 0
+    deadline = time.time() + 30
+    while moved < n and time.time() < deadline:
+        while fed < n and fed - moved < 200:
+            mem.feed((s0[fed], [fed % 6], [float(fed)], [0.95], s1[fed], float(fed % 7 == 0)), priority=1.0 + fed)
+            fed += 1
+        moved += mem.drain()
+    assert moved == n and mem.size == n
+    torch.cuda.synchronize()
+    assert torch.equal(mem.state0s[:n].cpu(), torch.as_tensor(s0))
+    assert torch.equal(mem.state1s[:n].cpu(), torch.as_tensor(s1))
+    assert torch.equal(mem.rewards[:n, 0].cpu(), torch.arange(n, dtype=torch.float32))
+    assert torch.equal(mem.actions[:n, 0].cpu(), (torch.arange(n) % 6).float())
+    leaves = mem.tree.get(torch.arange(n, device="cuda")).cpu()
+    want = (torch.arange(n, dtype=torch.float32) + 1.0 + mem.priority_eps) ** mem.priority_exponent
+    assert torch.allclose(leaves, want, rtol=1e-4)
+    assert abs(float(mem.tree.total()) - float(want.sum())) < 1e-2 * float(want.sum())
+    mem.close()
