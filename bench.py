@@ -179,6 +179,8 @@ def main():
         }
         out.update(extra)
         print(json.dumps(out), flush=True)
+    if hasattr(memory, "close"):
+        memory.close()
     comm.close()
 
 

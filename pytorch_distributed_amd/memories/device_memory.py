@@ -112,6 +112,8 @@ class DeviceMemory(Memory):
             if not self.pump:
                 raise RuntimeError("ingestion pump could not attach to the ring")
             self._pump_n = ctypes.c_int(0)
+            import atexit
+            atexit.register(self.close)     # the pump thread must stop before the ring's mapping goes away
         self._pos_base = torch.arange(self.ingest_chunk, device=dev, dtype=torch.int64)
         self.tree = DeviceSumMinTree(m, dev) if self.enable_per else None
         self._gen = torch.Generator(device=dev)
@@ -191,6 +193,12 @@ class DeviceMemory(Memory):
             self.ingest_records(self.staging_dev[i], n)
             moved += n
         return moved
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def close(self):
         if getattr(self, "pump", None):

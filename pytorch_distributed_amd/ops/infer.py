@@ -97,6 +97,8 @@ class NativeInferenceServer(object):
         if not self.handle:
             raise RuntimeError("native inference server could not be built (see stderr)")
         self._stream = torch.cuda.ExternalStream(int(_L().pda_infer_stream(self.handle)), device=self.device)
+        import atexit
+        atexit.register(self.stop)      # the loop thread must not outlive the mailbox mapping
         return self
 
     def build_cnn(self, weights, geom, norm_val, model=None):
