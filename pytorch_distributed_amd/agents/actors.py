@@ -18,7 +18,7 @@ import torch
 
 from ..utils.helpers import reset_experience
 from ..utils.param_store import sync_params
-from .nstep import NStepAssembler
+from .nstep import make_feeder
 
 
 def actor_epsilon(process_ind, num_actors, eps, eps_alpha):
@@ -91,7 +91,8 @@ def _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model
             return a + noise, q, mq
         return local_model.get_action(state, noise, device=local_device)
 
-    assembler = NStepAssembler(ap.nstep, ap.gamma, enable_per)
+    feeder = make_feeder(global_memory, ap.nstep, ap.gamma, enable_per,
+                         native=getattr(args, "native_nstep", True))
     experience = reset_experience()
     step = 0
     episode_steps, episode_reward = 0, 0.0
@@ -102,16 +103,14 @@ def _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model
             episode_steps, episode_reward = 0, 0.0
             experience = env.reset()
             assert experience.state1 is not None
-            assembler.reset(experience.state1)
+            feeder.reset(experience.state1)
             flag_reset = False
 
         action, qvalue, max_qvalue = act(experience.state1)
         experience = env.step(action)
 
-        for transition, priority in assembler.push(experience.action, experience.reward,
-                                                   experience.state1, experience.terminal1,
-                                                   qvalue, max_qvalue):
-            global_memory.feed(transition, priority)
+        feeder.push(experience.action, experience.reward, experience.state1, experience.terminal1,
+                    qvalue, max_qvalue)
 
         if experience.terminal1:
             nepisodes_solved += 1
@@ -127,8 +126,7 @@ def _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model
                 else:
                     _, _, max_q_last = local_model.get_action(experience.state1, True, eps,
                                                               device=local_device, rng=rng)
-            for transition, priority in assembler.flush(max_q_last):
-                global_memory.feed(transition, priority)
+            feeder.flush(max_q_last)
 
         with global_logs.actor_step.get_lock():
             global_logs.actor_step.value += 1

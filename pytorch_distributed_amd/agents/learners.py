@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from ..parallel.comm import SingleComm, make_comm
 from ..utils.helpers import update_target_model
-from ..utils.param_store import publish_params, sync_params
+from ..utils.param_store import AsyncParamPublisher, sync_params
 
 
 def _clip_value_(params, clip):
@@ -176,7 +176,10 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
     torch.manual_seed(args.seed + 1000 * rank)
     np.random.seed(args.seed + 1000 * rank)
 
-    comm = make_comm(rank, world, local_device, port=getattr(args, "dist_port", None))
+    from ..parallel.weight_sync import WeightPublisher, resolve_weight_sync
+    collective_sync = resolve_weight_sync(args) == "collective"
+    comm = make_comm(rank, world, local_device, port=getattr(args, "dist_port", None),
+                     extra_ranks=1 if collective_sync else 0)
 
     def build():
         return model_prototype(args.model_params, args.norm_val, args.state_shape,
@@ -200,6 +203,14 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
         if resolve_placement(args) == "learner":
             hosted = _host_inference(args, core, local_model, global_model.mailbox, local_device)
 
+    # weight hand-off (rank 0): seqlocked host buffer for evaluator / local actors (asynchronous D2H),
+    # plus a collective broadcast to the inference rank when it owns another GPU
+    shm_pub = AsyncParamPublisher(global_model, local_device) if rank == 0 else None
+    bcast_pub = None
+    if rank == 0 and collective_sync:
+        bcast_pub = WeightPublisher(comm, core.flat_params().numel(), local_device)
+        bcast_pub.publish(core.flat_params())
+
     step = 0
     started = False
     while step < ap.steps and not global_logs.stop.value:
@@ -217,14 +228,19 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
             with global_logs.learner_step.get_lock():
                 global_logs.learner_step.value += 1
             if step % args.param_sync_freq == 0 or step == ap.steps:
-                publish_params(global_model, core.flat_params())
+                if shm_pub.publish(core.flat_params()) and bcast_pub is not None:
+                    bcast_pub.publish(core.flat_params())
             if step % ap.learner_freq == 0:
                 for name, val in core.loss_values().items():
                     getattr(learner_logs, name).value += val
                 learner_logs.loss_counter.value += 1
                 global_logs.beat("learner")
     if rank == 0:
-        publish_params(global_model, core.flat_params())
+        shm_pub.publish(core.flat_params(), force=True)
+        shm_pub.close()
+        if bcast_pub is not None:
+            bcast_pub.publish(core.flat_params())
+            bcast_pub.close()
     if hasattr(global_memory, "close"):
         global_memory.close()
     if hosted is not None:

@@ -82,3 +82,89 @@ def nstep_batch_returns(rewards, gamma):
     k = rewards.shape[-1]
     disc = gamma ** np.arange(k)
     return (rewards * disc).sum(-1), gamma ** k
+
+
+class PythonFeeder(object):
+    """NStepAssembler + memory.feed(): works with every memory type."""
+
+    def __init__(self, memory, nstep, gamma, enable_per=False):
+        self.memory = memory
+        self.assembler = NStepAssembler(nstep, gamma, enable_per)
+
+    def reset(self, state):
+        self.assembler.reset(state)
+
+    def push(self, action, reward, state1, terminal1, qvalue=None, max_qvalue=None):
+        n = 0
+        for transition, priority in self.assembler.push(action, reward, state1, terminal1, qvalue, max_qvalue):
+            self.memory.feed(transition, priority)
+            n += 1
+        return n
+
+    def flush(self, max_qvalue_last=None):
+        n = 0
+        for transition, priority in self.assembler.flush(max_qvalue_last):
+            self.memory.feed(transition, priority)
+            n += 1
+        return n
+
+
+class NativeFeeder(object):
+    """The same bookkeeping in C (parallel/csrc/shm_ring.cpp, pda_nstep_*): the window of states
+    lives in the native object and finished transitions go straight into the ingestion ring as
+    packed records.  For ring-fed memories (memory_type "device*")."""
+
+    def __init__(self, memory, nstep, gamma, enable_per=False, timeout_s=30.0):
+        from ..parallel import hostlib
+        self.L = hostlib.lib()
+        c = memory.codec
+        self.codec, self.ring = c, memory.ring
+        self.state_np = c.state_np
+        self.timeout_ms = int(timeout_s * 1000)
+        self.h = self.L.pda_nstep_create(int(nstep), float(gamma), 1 if enable_per else 0, c.state_bytes,
+                                         c.state_stride, c.action_shape, c.num_tasks, c.record_bytes)
+        if not self.h:
+            raise ValueError("n-step assembler: inconsistent record layout")
+        self._act = np.zeros(c.action_shape, dtype=np.float32)
+
+    def _state(self, s):
+        return np.ascontiguousarray(s, dtype=self.state_np)
+
+    def reset(self, state):
+        s = self._state(state)
+        self.L.pda_nstep_reset(self.h, s.ctypes.data)
+
+    def _check(self, rc):
+        if rc == -1:
+            raise RuntimeError("replay ingestion ring stayed full for %d s (is a learner draining it?)"
+                               % (self.timeout_ms // 1000))
+        if rc < 0:
+            raise ValueError("record larger than ring payload")
+        return rc
+
+    def push(self, action, reward, state1, terminal1, qvalue=None, max_qvalue=None):
+        s = self._state(state1)
+        self._act[:] = np.asarray(action, dtype=np.float32).reshape(-1)
+        has_q = qvalue is not None and max_qvalue is not None
+        return self._check(self.L.pda_nstep_push(
+            self.h, self.ring.base, self._act.ctypes.data, float(reward), s.ctypes.data, int(bool(terminal1)),
+            float(qvalue) if has_q else 0.0, float(max_qvalue) if has_q else 0.0, int(has_q), self.timeout_ms))
+
+    def flush(self, max_qvalue_last=None):
+        has = max_qvalue_last is not None
+        return self._check(self.L.pda_nstep_flush(self.h, self.ring.base, float(max_qvalue_last) if has else 0.0,
+                                                  int(has), self.timeout_ms))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.pda_nstep_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def make_feeder(memory, nstep, gamma, enable_per=False, native=True):
+    if native and hasattr(memory, "ring") and hasattr(memory, "codec"):
+        return NativeFeeder(memory, nstep, gamma, enable_per)
+    return PythonFeeder(memory, nstep, gamma, enable_per)

@@ -124,7 +124,8 @@ def run(opt):
             p.join()
         return sup
 
-    if opt.num_learners > 1 and not hasattr(opt, "dist_port"):
+    from .parallel.weight_sync import resolve_weight_sync
+    if (opt.num_learners > 1 or resolve_weight_sync(opt) == "collective") and not hasattr(opt, "dist_port"):
         opt.dist_port = 29500 + (os.getpid() % 2000)
     global_memory = memory_prototype(opt.memory_params)
     global_model = build_global_model(opt)

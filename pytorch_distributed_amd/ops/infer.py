@@ -139,6 +139,14 @@ class NativeInferenceServer(object):
             self.weights.refresh()
         return version
 
+    def refresh_from_receiver(self, receiver):
+        """Same, with the snapshot that arrived by collective broadcast (parallel/weight_sync.py)."""
+        with torch.cuda.stream(self._stream):
+            if receiver.poll_into(self.model.flat_params):
+                self.weights.refresh()
+                return True
+        return False
+
     # ---- serving ------------------------------------------------------------------------------
     def serve_once(self):
         with torch.cuda.device(self.device):

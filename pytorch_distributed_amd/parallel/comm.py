@@ -56,16 +56,23 @@ class SingleComm(object):
 class TorchComm(SingleComm):
     """torch.distributed-backed communicator (RCCL on GPU, gloo on CPU)."""
 
-    def __init__(self, rank, world_size, device, init_method=None, backend=None, timeout_s=600):
+    def __init__(self, rank, world_size, device, init_method=None, backend=None, timeout_s=600, extra_ranks=0):
+        """`extra_ranks` more processes join the same process group after the `world_size` learner
+        ranks (the inference server receiving weight broadcasts, parallel/weight_sync.py).  The
+        learners' collectives then run on a sub-group of ranks [0, world_size) and
+        `self.weight_group` = {0, world_size, ...} carries the learner -> inference broadcast."""
         import datetime
         self.rank, self.world_size = rank, world_size
+        self.total_ranks = world_size + int(extra_ranks)
+        self.group = None
+        self.weight_group = None
         self.device = torch.device(device)
         if backend is None:
             backend = "nccl" if self.device.type == "cuda" else "gloo"
         self.backend = backend
         self.owns_group = False
         if not dist.is_initialized():
-            kwargs = dict(backend=backend, rank=rank, world_size=world_size,
+            kwargs = dict(backend=backend, rank=rank, world_size=self.total_ranks,
                           timeout=datetime.timedelta(seconds=timeout_s))
             if init_method is not None:
                 kwargs["init_method"] = init_method
@@ -77,6 +84,9 @@ class TorchComm(SingleComm):
                     pass
             dist.init_process_group(**kwargs)
             self.owns_group = True
+        if extra_ranks:     # every process of the world creates both groups, in this order
+            self.group = dist.new_group(ranks=list(range(world_size)))
+            self.weight_group = dist.new_group(ranks=[0] + list(range(world_size, self.total_ranks)))
         self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
@@ -87,10 +97,10 @@ class TorchComm(SingleComm):
         if self.comm_stream is not None and async_op:
             self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
                 flat.mul_(1.0 / self.world_size)
             return self.comm_stream
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.mul_(1.0 / self.world_size)
         return None
 
@@ -99,23 +109,23 @@ class TorchComm(SingleComm):
             torch.cuda.current_stream(self.device).wait_stream(handle)
 
     def all_reduce_sum_(self, flat):
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
     def broadcast_(self, flat, src=0):
-        dist.broadcast(flat, src=src)
+        dist.broadcast(flat, src=src, group=self.group)
         return flat
 
     def all_agree(self, flag):
         self._flag.fill_(1 if flag else 0)
-        dist.all_reduce(self._flag, op=dist.ReduceOp.MIN)
+        dist.all_reduce(self._flag, op=dist.ReduceOp.MIN, group=self.group)
         return bool(self._flag.item())
 
     def barrier(self):
         if self.device.type == "cuda":
-            dist.barrier(device_ids=[self.device.index if self.device.index is not None else 0])
+            dist.barrier(group=self.group, device_ids=[self.device.index if self.device.index is not None else 0])
         else:
-            dist.barrier()
+            dist.barrier(group=self.group)
 
     def close(self):
         if self.owns_group and dist.is_initialized():
@@ -170,11 +180,15 @@ class FakeComm(SingleComm):
         return flat
 
 
-def make_comm(rank, world_size, device, port=None, backend=None):
-    if world_size <= 1:
+def make_comm(rank, world_size, device, port=None, backend=None, extra_ranks=0):
+    """Learner rank `rank` of `world_size`; `extra_ranks` non-learner processes (inference server)
+    share the process group for weight broadcasts (they call make_comm with rank >= world_size)."""
+    if world_size + extra_ranks <= 1:
         return SingleComm()
     port = port or int(os.environ.get("PDA_DIST_PORT", "29533"))
-    return TorchComm(rank, world_size, device, init_method="tcp://127.0.0.1:%d" % port, backend=backend)
+    # a posted weight broadcast legitimately waits as long as the learner has nothing to publish
+    return TorchComm(rank, world_size, device, init_method="tcp://127.0.0.1:%d" % port, backend=backend,
+                     extra_ranks=extra_ranks, timeout_s=86400 if extra_ranks else 600)
 
 
 def comm_from_env(device, backend=None, force=False):

@@ -286,6 +286,166 @@ void pda_pump_destroy(void* h) {
     delete P;
 }
 
+// ---- n-step transition assembly (kernel K11, host form) ------------------------------------
+// The reference assembles n-step transitions in Python deques inside every actor
+// (dqn_actor.py:55-61,110-163).  Here one C object per env keeps the window of the last
+// nstep+2 states / nstep+1 (action, reward, terminal, q, max q) and writes finished
+// transitions straight into the ingestion ring as packed records (scatter-gather from the
+// window: no intermediate arrays, no Python per transition).  Bookkeeping is the reference's:
+//   * >= 3 states buffered: every step emits the LAGGED transition
+//       (s[0], a[0], sum_{i < len(r)-1} gamma^i r_i, gamma^(len(s)-2), s[-2], t[-2])
+//   * episode end: exactly one more, reaching the true last state, from s[1] if the window is
+//     full, else from s[0]
+//   * PER initial priority |R + gamma^k max_a Q(s_k) - Q(s0, a0)| from the actor's own network
+}  // extern "C"
+
+namespace {
+
+struct NStep {
+    int nstep; double gamma; bool per;
+    uint32_t state_bytes, state_stride; int A, T; uint32_t record_bytes;
+    int cap_s, cap_o;                    // window capacities: nstep + 2 states, nstep + 1 others
+    std::vector<char> pool;              // cap_s state slots of state_stride bytes (pad stays zero)
+    std::vector<int> s_slot;             // window order -> pool slot
+    int n_s = 0, n_o = 0;
+    std::vector<float> actions;          // [cap_o][A]
+    std::vector<double> rewards, qs, maxqs;
+    std::vector<float> terms;
+    std::vector<char> has_q;
+    std::vector<float> tail;
+    uint64_t emitted = 0;
+};
+
+char* ns_state(NStep* N, int i) { return N->pool.data() + (size_t)N->s_slot[i] * N->state_stride; }
+
+void ns_append_state(NStep* N, const void* st) {
+    int slot;
+    if (N->n_s == N->cap_s) {            // drop the oldest, reuse its slot
+        slot = N->s_slot[0];
+        for (int i = 1; i < N->n_s; ++i) N->s_slot[i - 1] = N->s_slot[i];
+        N->n_s -= 1;
+    } else {
+        // free slot = one not referenced by the window
+        std::vector<char> used(N->cap_s, 0);
+        for (int i = 0; i < N->n_s; ++i) used[N->s_slot[i]] = 1;
+        slot = 0;
+        while (used[slot]) ++slot;
+    }
+    std::memcpy(N->pool.data() + (size_t)slot * N->state_stride, st, N->state_bytes);
+    N->s_slot[N->n_s++] = slot;
+}
+
+int ns_emit(NStep* N, void* ring, int first, int last_state, int term_idx, double ret, double gamma_sn,
+            double prio, uint32_t timeout_ms) {
+    float* t = N->tail.data();
+    int A = N->A, T = N->T;
+    for (int j = 0; j < A; ++j) t[j] = N->actions[(size_t)first * A + j];
+    for (int j = 0; j < T; ++j) {
+        t[A + j] = (float)ret;
+        t[A + T + j] = (float)gamma_sn;
+        t[A + 2 * T + j] = N->terms[term_idx];
+    }
+    t[A + 3 * T] = (float)prio;
+    uint32_t tail_bytes = N->record_bytes - 2 * N->state_stride;
+    uint32_t waited_us = 0, delay = 10;
+    for (;;) {
+        int rc = pda_ring_push(ring, ns_state(N, first), N->state_stride, ns_state(N, last_state), N->state_stride,
+                               t, tail_bytes, nullptr, 0);
+        if (rc == 1) { N->emitted += 1; return 1; }
+        if (rc < 0) return -2;
+        if (waited_us / 1000 >= timeout_ms) return -1;      // ring stayed full: the learner is not draining
+        std::this_thread::sleep_for(std::chrono::microseconds(delay));
+        waited_us += delay;
+        if (delay < 2000) delay *= 2;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void* pda_nstep_create(int nstep, double gamma, int enable_per, uint32_t state_bytes, uint32_t state_stride,
+                       int action_floats, int num_tasks, uint32_t record_bytes) {
+    if (nstep < 1 || state_stride < state_bytes) return nullptr;
+    uint32_t tail_floats = (uint32_t)(action_floats + 3 * num_tasks + 1);
+    if (record_bytes < 2 * state_stride + 4 * tail_floats) return nullptr;
+    NStep* N = new NStep();
+    N->nstep = nstep; N->gamma = gamma; N->per = enable_per != 0;
+    N->state_bytes = state_bytes; N->state_stride = state_stride; N->A = action_floats; N->T = num_tasks;
+    N->record_bytes = record_bytes;
+    N->cap_s = nstep + 2; N->cap_o = nstep + 1;
+    N->pool.assign((size_t)N->cap_s * state_stride, 0);
+    N->s_slot.assign(N->cap_s, 0);
+    N->actions.assign((size_t)N->cap_o * action_floats, 0.f);
+    N->rewards.assign(N->cap_o, 0.0); N->qs.assign(N->cap_o, 0.0); N->maxqs.assign(N->cap_o, 0.0);
+    N->terms.assign(N->cap_o, 0.f); N->has_q.assign(N->cap_o, 0);
+    N->tail.assign((record_bytes - 2 * state_stride) / 4 + 4, 0.f);
+    return N;
+}
+void pda_nstep_destroy(void* h) { delete static_cast<NStep*>(h); }
+uint64_t pda_nstep_emitted(void* h) { return static_cast<NStep*>(h)->emitted; }
+
+void pda_nstep_reset(void* h, const void* state) {
+    NStep* N = static_cast<NStep*>(h);
+    N->n_s = 0; N->n_o = 0;
+    ns_append_state(N, state);
+}
+
+// One env step.  Returns the number of transitions written to the ring (0 or 1), -1 if the ring
+// stayed full for timeout_ms, -2 on a size mismatch.
+int pda_nstep_push(void* h, void* ring, const float* action, double reward, const void* state1, int terminal,
+                   double q, double maxq, int has_q, uint32_t timeout_ms) {
+    NStep* N = static_cast<NStep*>(h);
+    ns_append_state(N, state1);
+    if (N->n_o == N->cap_o) {            // slide the (action, reward, ...) window
+        int A = N->A;
+        for (int i = 1; i < N->n_o; ++i) {
+            for (int j = 0; j < A; ++j) N->actions[(size_t)(i - 1) * A + j] = N->actions[(size_t)i * A + j];
+            N->rewards[i - 1] = N->rewards[i]; N->qs[i - 1] = N->qs[i]; N->maxqs[i - 1] = N->maxqs[i];
+            N->terms[i - 1] = N->terms[i]; N->has_q[i - 1] = N->has_q[i];
+        }
+        N->n_o -= 1;
+    }
+    int k = N->n_o++;
+    for (int j = 0; j < N->A; ++j) N->actions[(size_t)k * N->A + j] = action[j];
+    N->rewards[k] = reward; N->terms[k] = terminal ? 1.f : 0.f;
+    N->qs[k] = q; N->maxqs[k] = maxq; N->has_q[k] = (char)(has_q != 0);
+    if (N->n_s < 3) return 0;
+    double ret = 0.0, g = 1.0;
+    for (int i = 0; i < N->n_o - 1; ++i) { ret += N->rewards[i] * g; g *= N->gamma; }
+    double gamma_sn = 1.0;
+    for (int i = 0; i < N->n_s - 2; ++i) gamma_sn *= N->gamma;
+    double prio = 0.0;
+    if (N->per && N->has_q[N->n_o - 1] && N->has_q[0]) {
+        prio = ret + gamma_sn * N->maxqs[N->n_o - 1] - N->qs[0];
+        if (prio < 0) prio = -prio;
+    }
+    return ns_emit(N, ring, 0, N->n_s - 2, N->n_o - 2, ret, gamma_sn, prio, timeout_ms);
+}
+
+// Episode ended: emit the one closing transition (see the header comment).
+int pda_nstep_flush(void* h, void* ring, double maxq_last, int has_maxq, uint32_t timeout_ms) {
+    NStep* N = static_cast<NStep*>(h);
+    if (N->n_o == 0) return 0;
+    int first;
+    double ret = 0.0, g = 1.0, gamma_sn = 1.0;
+    if (N->n_s >= N->nstep + 2) {
+        first = 1;
+        for (int i = 1; i < N->n_o; ++i) { ret += N->rewards[i] * g; g *= N->gamma; }
+        for (int i = 0; i < N->n_s - 2; ++i) gamma_sn *= N->gamma;
+    } else {
+        first = 0;
+        for (int i = 0; i < N->n_o; ++i) { ret += N->rewards[i] * g; g *= N->gamma; }
+        for (int i = 0; i < N->n_s - 1; ++i) gamma_sn *= N->gamma;
+    }
+    double prio = 0.0;
+    if (N->per && has_maxq && N->has_q[first]) {
+        prio = ret + gamma_sn * maxq_last - N->qs[first];
+        if (prio < 0) prio = -prio;
+    }
+    return ns_emit(N, ring, first, N->n_s - 1, N->n_o - 1, ret, gamma_sn, prio, timeout_ms);
+}
+
 // ---- inference mailbox (protocol in mailbox.h) ------------------------------------------
 // Actor: copy the observation into its slot, post request number `k`, wait for the answer.
 // Returns the last resp value seen (>= k once answered); on a smaller value the caller checks

@@ -62,6 +62,19 @@ def lib():
         L.pda_pump_moved.argtypes = [vp]
         L.pda_pump_destroy.restype = None
         L.pda_pump_destroy.argtypes = [vp]
+        dbl = ctypes.c_double
+        L.pda_nstep_create.restype = vp
+        L.pda_nstep_create.argtypes = [i32, dbl, i32, u32, u32, i32, i32, u32]
+        L.pda_nstep_destroy.restype = None
+        L.pda_nstep_destroy.argtypes = [vp]
+        L.pda_nstep_emitted.restype = u64
+        L.pda_nstep_emitted.argtypes = [vp]
+        L.pda_nstep_reset.restype = None
+        L.pda_nstep_reset.argtypes = [vp, vp]
+        L.pda_nstep_push.restype = i32
+        L.pda_nstep_push.argtypes = [vp, vp, vp, dbl, vp, i32, dbl, dbl, i32, u32]
+        L.pda_nstep_flush.restype = i32
+        L.pda_nstep_flush.argtypes = [vp, vp, dbl, i32, u32]
         L.pda_mailbox_request.restype = u64
         L.pda_mailbox_request.argtypes = [vp, i32, u64, vp, vp, u64, u32, u32]
         L.pda_mailbox_wait.restype = u64

@@ -182,8 +182,9 @@ def _native_server(args, model, mailbox, device):
 
 def inference_server(process_ind, args, global_logs, model_prototype, global_model):
     print("---------------------------->", process_ind, "inference server")
+    from .weight_sync import WeightReceiver, inference_device, resolve_weight_sync
     mailbox = global_model.mailbox
-    device = torch.device(args.device if args.device != "cuda" else "cuda:%d" % args.gpu_ind)
+    device = inference_device(args)
     if device.type == "cuda":
         torch.cuda.set_device(device)
     model = model_prototype(args.model_params, args.norm_val, args.state_shape,
@@ -191,24 +192,38 @@ def inference_server(process_ind, args, global_logs, model_prototype, global_mod
     version = sync_params(model, global_model)
     model.eval()
     torch.set_grad_enabled(False)
+    receiver = None
+    if resolve_weight_sync(args) == "collective":
+        # join the learners' process group as rank L; weights then arrive by broadcast from rank 0
+        from .comm import make_comm
+        comm = make_comm(args.num_learners, args.num_learners, device, port=getattr(args, "dist_port", None),
+                         extra_ranks=1)
+        receiver = WeightReceiver(comm, model.flatten_(with_grad=False).numel(), device)
     try:
         native = _native_server(args, model, mailbox, device)
         if native is not None:
-            _serve_native(args, global_logs, global_model, native, version)
+            _serve_native(args, global_logs, global_model, native, version, receiver=receiver)
         else:
             policy = BatchedPolicy(args, model, device)
             policy.refresh()
-            _serve(args, global_logs, global_model, mailbox, model, policy, device, version)
+            _serve(args, global_logs, global_model, mailbox, model, policy, device, version, receiver=receiver)
     finally:
         mailbox.closed[0] = 1
+        if receiver is not None:
+            receiver.join(20)
+            print("[inference] %d weight broadcasts received" % receiver.version, flush=True)
+            comm.close()
 
 
-def _serve_native(args, global_logs, global_model, native, version, poll_s=0.02):
+def _serve_native(args, global_logs, global_model, native, version, poll_s=0.02, receiver=None):
     """The C++ loop thread answers the actors; this thread only re-syncs the weights."""
     native.start()
     try:
         while global_logs.running(args.agent_params.steps):
             time.sleep(poll_s)
+            if receiver is not None:
+                native.refresh_from_receiver(receiver)
+                continue
             v = global_model.param_version.value
             if v != version and v % 2 == 0:
                 version = native.refresh_from(global_model)
@@ -221,7 +236,7 @@ def _serve_native(args, global_logs, global_model, native, version, poll_s=0.02)
         native.close()
 
 
-def _serve(args, global_logs, global_model, mailbox, model, policy, device, version):
+def _serve(args, global_logs, global_model, mailbox, model, policy, device, version, receiver=None):
     eps_dev = None
     served, last_sync = 0, 0
     idle = 0
@@ -242,8 +257,12 @@ def _serve(args, global_logs, global_model, mailbox, model, policy, device, vers
         mailbox.respond(ids, req_seen, actions, q, mq)
         served += len(ids)
         if served - last_sync >= args.agent_params.actor_sync_freq:
-            v = global_model.param_version.value
-            if v != version and v % 2 == 0:
-                version = sync_params(model, global_model)
-                policy.refresh()
+            if receiver is not None:
+                if receiver.poll_into(model.flat_params):
+                    policy.refresh()
+            else:
+                v = global_model.param_version.value
+                if v != version and v % 2 == 0:
+                    version = sync_params(model, global_model)
+                    policy.refresh()
             last_sync = served

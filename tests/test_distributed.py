@@ -229,3 +229,67 @@ def test_ddpg_dp_equivalence_fake_comm():
     # gradient element reaches the clip (40), which holds for this data
     for core in cores:
         assert _same_params(core.model.flat_params, single.model.flat_params)
+
+
+def _weight_sync_worker(rank, port, out_q):
+    """2 learner ranks + 1 inference rank in one gloo world: sub-group collectives + weight broadcast."""
+    from pytorch_distributed_amd.parallel.weight_sync import WeightPublisher, WeightReceiver
+    learners = 2
+    comm = make_comm(rank, learners, torch.device("cpu"), port=port, extra_ranks=1)
+    n = 1000
+    ok = True
+    if rank < learners:
+        t = torch.full((8,), float(rank + 1))
+        comm.all_reduce_sum_(t)                 # only the two learners take part
+        ok = ok and bool(torch.equal(t, torch.full((8,), 3.0))) and comm.all_agree(True)
+        if rank == 0:
+            pub = WeightPublisher(comm, n, torch.device("cpu"))
+            for k in range(1, 6):
+                pub.publish(torch.full((n,), float(k)))
+            pub.close()
+        out_q.put((rank, ok, 0))
+    else:
+        recv = WeightReceiver(comm, n, torch.device("cpu"))
+        flat = torch.zeros(n)
+        seen = []
+        import time
+        deadline = time.time() + 60
+        while not recv.closed and time.time() < deadline:
+            if recv.poll_into(flat):
+                seen.append(float(flat[0]))
+            time.sleep(0.001)
+        if recv.poll_into(flat):
+            seen.append(float(flat[0]))
+        recv.join(10)
+        ok = recv.closed and recv.version == 5 and seen[-1] == 5.0 and seen == sorted(seen) \
+            and bool(torch.equal(flat, torch.full((n,), 5.0)))
+        out_q.put((rank, ok, recv.version))
+    comm.close()
+
+
+def test_weight_broadcast_to_inference_rank_gloo():
+    port = free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_weight_sync_worker, args=(r, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(3)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in results), results
+
+
+def test_collective_weight_sync_job_through_launcher(tmp_root):
+    """Batched inference server as rank L of the learners' group: weights arrive by broadcast (gloo here,
+    RCCL when the server owns a GPU), actions still flow through the mailbox."""
+    from tests.test_integration import FAST
+    o = dict(FAST)
+    o.update({"root_dir": tmp_root, "timestamp": "wsync", "num_actors": 2, "actor_inference": "batched",
+              "weight_sync": "collective", "dist_port": free_port(),
+              "agent_params.steps": 40, "agent_params.learn_start": 60})
+    opt = Options(config=6, overrides=o)
+    sup = run(opt)
+    assert all(c == 0 for c in sup.exitcodes), sup.exitcodes
+    assert os.path.exists(opt.model_name)

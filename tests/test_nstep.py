@@ -94,3 +94,57 @@ def test_epsilon_ladder():
 def test_batch_returns():
     r, g = nstep_batch_returns(np.array([[1.0, 2.0, 3.0]]), 0.5)
     assert r[0] == pytest.approx(1 + 1 + 0.75) and g == pytest.approx(0.125)
+
+
+@pytest.mark.parametrize("nstep,per,dtype", [(1, False, "uint8"), (5, True, "uint8"), (3, True, "float32")])
+def test_native_feeder_matches_python_assembler(nstep, per, dtype):
+    """C n-step assembler (pda_nstep_*) == NStepAssembler + DeviceMemory.feed, record for record."""
+    import torch
+    from pytorch_distributed_amd.agents.nstep import NativeFeeder, PythonFeeder
+    from pytorch_distributed_amd.launcher import prepare_options
+    from pytorch_distributed_amd.memories.device_memory import DeviceMemory
+    from pytorch_distributed_amd.utils.options import Options
+    cfg = 4 if dtype == "uint8" else 7
+    opt = prepare_options(Options(config=cfg, overrides={"device": "cpu", "memory_params.memory_size": 64,
+                                                         "memory_params.ingest_ring_slots": 256,
+                                                         "memory_params.replay_device": "cpu"}))
+    mems = [DeviceMemory(opt.memory_params), DeviceMemory(opt.memory_params)]
+    gamma = 0.97
+    feeders = [PythonFeeder(mems[0], nstep, gamma, per), NativeFeeder(mems[1], nstep, gamma, per)]
+    rng = np.random.RandomState(nstep)
+    shape = tuple(opt.state_shape)
+    A = int(opt.action_shape)
+
+    def state():
+        if dtype == "uint8":
+            return rng.randint(0, 256, size=shape).astype(np.uint8)
+        return rng.randn(*shape).astype(np.float32)
+
+    counts = [0, 0]
+    for length in (1, 2, 3, nstep + 1, nstep + 2, 11):
+        s = state()
+        for f in feeders:
+            f.reset(s)
+        for t in range(length):
+            a = rng.randint(0, 3, size=(1, A)).astype(np.float64)
+            r, s1, term = float(rng.randn()), state(), bool(t == length - 1 and length % 2)
+            q, mq = float(rng.randn()), float(rng.randn())
+            for i, f in enumerate(feeders):
+                counts[i] += f.push(a, r, s1, term, q, mq)
+        mq_last = float(rng.randn())
+        for i, f in enumerate(feeders):
+            counts[i] += f.flush(mq_last if per else None)
+    assert counts[0] == counts[1] > 0
+    c = mems[0].codec
+    bufs = []
+    for m in mems:
+        out = torch.zeros(counts[0] + 4, c.record_bytes, dtype=torch.uint8)
+        assert m.ring.pop_many(out, counts[0] + 4) == counts[0]
+        bufs.append(out[:counts[0]].numpy())
+    a, b = bufs
+    assert np.array_equal(a[:, :c.tail_offset], b[:, :c.tail_offset])            # both states, byte for byte
+    ta = a[:, c.tail_offset:c.tail_offset + 4 * c.tail_floats].copy().view(np.float32)
+    tb = b[:, c.tail_offset:c.tail_offset + 4 * c.tail_floats].copy().view(np.float32)
+    np.testing.assert_allclose(ta, tb, rtol=1e-6, atol=1e-6)
+    if per:
+        assert (ta[:, -1] > 0).any()
