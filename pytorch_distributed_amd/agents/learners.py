@@ -74,6 +74,33 @@ class _TorchCore(object):
     def loss_values(self):
         return {k: float(v) for k, v in self.last_losses.items()}
 
+    # ---- true resume (the reference can only warm-start from the plain state_dict) ----------
+    def resume_state(self):
+        st = self.optimizer.state_dict()["state"]
+        keys = sorted(st)
+        out = {"kind": "torch", "params": self.model.flat_params.detach().cpu().clone(),
+               "target": self.target_model.flat_params.detach().cpu().clone(), "step_count": self.step_count}
+        if keys:
+            out["exp_avg"] = torch.cat([st[k]["exp_avg"].reshape(-1).cpu() for k in keys])
+            out["exp_avg_sq"] = torch.cat([st[k]["exp_avg_sq"].reshape(-1).cpu() for k in keys])
+            out["opt_step"] = int(st[keys[0]]["step"])
+        return out
+
+    def load_resume_state(self, d):
+        with torch.no_grad():
+            self.model.flat_params.copy_(d["params"])
+            self.target_model.flat_params.copy_(d["target"])
+        self.step_count = int(d["step_count"])
+        if "exp_avg" in d:
+            off = 0
+            for p in self.model.parameters():        # materialise the optimizer state, then overwrite it
+                n = p.numel()
+                state = self.optimizer.state[p]
+                state["step"] = torch.tensor(float(d["opt_step"]))
+                state["exp_avg"] = d["exp_avg"][off:off + n].view_as(p).to(p.device).clone()
+                state["exp_avg_sq"] = d["exp_avg_sq"][off:off + n].view_as(p).to(p.device).clone()
+                off += n
+
 
 class DqnTorchCore(_TorchCore):
     def step(self):
@@ -148,6 +175,66 @@ def make_core(kind, args, model, target_model, memory, comm, device):
     return (DqnTorchCore if kind == "dqn" else DdpgTorchCore)(args, model, target_model, memory, comm)
 
 
+def native_resume_state(core):
+    """Resume blob of a native (HIP engine) core: fp32 masters, target, Adam moments (kernel layout),
+    the device-side step counter."""
+    e = core.engine
+    return {"kind": "native", "params": e.online.flat.detach().cpu().clone(),
+            "target": e.target.flat.detach().cpu().clone(), "exp_avg": e.adam.m.cpu().clone(),
+            "exp_avg_sq": e.adam.v.cpu().clone(), "opt_step": int(e.adam.step_dev.item()),
+            "step_count": int(getattr(e, "step_count", core.step_count))}
+
+
+def native_load_resume_state(core, d):
+    e = core.engine
+    with torch.no_grad():
+        e.online.flat.copy_(d["params"])
+        e.target.flat.copy_(d["target"])
+        e.adam.m.copy_(d["exp_avg"])
+        e.adam.v.copy_(d["exp_avg_sq"])
+        e.adam.step_dev.fill_(int(d["opt_step"]))
+    e.online.refresh()
+    e.target.refresh()
+    if hasattr(e, "step_count"):
+        e.step_count = int(d["step_count"])
+    core.step_count = int(d["step_count"])
+
+
+def _resume_path(args):
+    return args.model_name[:-4] + ".resume.pth" if args.model_name.endswith(".pth") else args.model_name + ".resume"
+
+
+def save_learner_resume(args, core, learner_step, actor_step):
+    from ..utils.checkpoint import save_resume
+    blob = core.resume_state() if hasattr(core, "resume_state") else native_resume_state(core)
+    blob["learner_step"], blob["actor_step"] = int(learner_step), int(actor_step)
+    save_resume(_resume_path(args), **blob)
+
+
+def load_learner_resume(args, core):
+    """Returns (learner_step, actor_step) restored from the sidecar, or None."""
+    import os
+    from ..utils.checkpoint import load_resume
+    path = _resume_path(args)
+    if not os.path.exists(path):
+        return None
+    d = load_resume(path)
+    native = not hasattr(core, "resume_state")
+    if (d.get("kind") == "native") != native:
+        print("[learner] resume file %s was written by the %s step back-end; only weights are restored"
+              % (path, d.get("kind")))
+        with torch.no_grad():
+            core.flat_params().copy_(d["params"])
+        if native:
+            core.engine.online.refresh()
+        return int(d["learner_step"]), int(d["actor_step"])
+    if native:
+        native_load_resume_state(core, d)
+    else:
+        core.load_resume_state(d)
+    return int(d["learner_step"]), int(d["actor_step"])
+
+
 def _host_inference(args, core, model, mailbox, device):
     engine = getattr(core, "engine", None)
     if device.type != "cuda" or engine is None or not hasattr(engine, "online"):
@@ -212,6 +299,15 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
         bcast_pub.publish(core.flat_params())
 
     step = 0
+    if getattr(args, "resume", False):
+        restored = load_learner_resume(args, core)      # every rank loads the same sidecar
+        if restored is not None:
+            step = restored[0]
+            if rank == 0:
+                global_logs.learner_step.value = restored[0]
+                global_logs.actor_step.value = restored[1]
+                print("[learner] resumed from %s at learner step %d" % (_resume_path(args), step))
+    resume_freq = int(getattr(args, "resume_freq", 0))
     started = False
     while step < ap.steps and not global_logs.stop.value:
         if hasattr(global_memory, "drain"):
@@ -230,12 +326,16 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
             if step % args.param_sync_freq == 0 or step == ap.steps:
                 if shm_pub.publish(core.flat_params()) and bcast_pub is not None:
                     bcast_pub.publish(core.flat_params())
+            if resume_freq and step % resume_freq == 0:
+                save_learner_resume(args, core, step, global_logs.actor_step.value)
             if step % ap.learner_freq == 0:
                 for name, val in core.loss_values().items():
                     getattr(learner_logs, name).value += val
                 learner_logs.loss_counter.value += 1
                 global_logs.beat("learner")
     if rank == 0:
+        if getattr(args, "save_resume", True):
+            save_learner_resume(args, core, step, global_logs.actor_step.value)
         shm_pub.publish(core.flat_params(), force=True)
         shm_pub.close()
         if bcast_pub is not None:

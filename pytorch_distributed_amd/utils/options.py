@@ -111,6 +111,9 @@ class Params(object):
         self.device = _default_device()     # learner / inference device: "cuda" | "cpu"
         self.actor_inference = "local"      # "local": per-actor model copy | "batched": GPU inference server
         self.inference_placement = "auto"   # batched inference runs in a "process" of its own | inside the "learner"
+        self.resume = False                 # continue from ./models/MACHINE_TIMESTAMP.resume.pth (optimizer, target, counters)
+        self.resume_freq = 0                # also write the resume sidecar every this many learner steps (0: only at the end)
+        self.save_resume = True
         self.native_nstep = True            # ring-fed memories: n-step assembly + record packing in C (K11)
         self.weight_sync = "auto"           # learner -> inference server weights: "shm" | "collective" (RCCL/gloo broadcast)
         self.actor_nice = 5                 # niceness added to actor processes (0 = leave alone)

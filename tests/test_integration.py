@@ -84,3 +84,20 @@ def test_supervisor_restarts_dead_actor(tmp_root):
     sup = run(opt)
     assert sup.restarts == 1
     assert os.path.exists(opt.model_name)
+
+
+def test_resume_sidecar_continues_training(tmp_root):
+    """True resume (absent in the reference): optimizer moments, target net and counters come back."""
+    from pytorch_distributed_amd.utils.checkpoint import load_resume
+    base = {"agent_params.learn_start": 60}
+    opt = opts(6, tmp_root, timestamp="res", **dict(base, **{"agent_params.steps": 30}))
+    run(opt)
+    side = opt.model_name[:-4] + ".resume.pth"
+    a = load_resume(side)
+    assert a["learner_step"] == 30 and a["opt_step"] == 30 and a["exp_avg"].abs().sum() > 0
+    opt2 = opts(6, tmp_root, timestamp="res", resume=True, **dict(base, **{"agent_params.steps": 50}))
+    sup = run(opt2)
+    assert all(c == 0 for c in sup.exitcodes), sup.exitcodes
+    b = load_resume(side)
+    assert b["learner_step"] == 50 and b["opt_step"] == 50          # 20 more optimizer steps, not 50
+    assert not torch.equal(a["params"], b["params"])
