@@ -87,6 +87,23 @@ def _L():
     return L
 
 
+class _Range(object):
+    """roctx range around a learner phase when PDA_ROCTX=1 (visible in rocprofv3 --marker-trace of an
+    eager, non-graph run); a no-op otherwise."""
+    enabled = bool(int(os.environ.get("PDA_ROCTX", "0") or 0))
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if self.enabled:
+            torch.cuda.nvtx.range_push(self.name)
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            torch.cuda.nvtx.range_pop()
+
+
 def _ksplit(red, tiles, target_blocks=768, minimum=64):
     """Split-K slice length (multiple of 32) so that tiles * slices ~ target_blocks."""
     slices = max(1, target_blocks // max(tiles, 1))
@@ -423,15 +440,20 @@ class DqnStepProgram(object):
 
     def _part_a(self):
         if not self.staged:
-            self.e.sample()
-        self.e.forward_head(self.staged)
-        self.e.backward_fc()
+            with _Range("learner/sample"):
+                self.e.sample()
+        with _Range("learner/forward+td_head"):
+            self.e.forward_head(self.staged)
+        with _Range("learner/backward_fc"):
+            self.e.backward_fc()
 
     def _part_b(self):
-        self.e.backward_conv(self.staged)
+        with _Range("learner/backward_conv"):
+            self.e.backward_conv(self.staged)
 
     def _part_c(self):
-        self.e.update(self.staged)
+        with _Range("learner/adam+target+tree"):
+            self.e.update(self.staged)
 
     def _whole(self):
         self._part_a()
