@@ -16,15 +16,19 @@
 //       fragments come back through ds_read_b64_tr_b16, CDNA4's transposing LDS
 //       read (two 4x16 blocks per fragment), so no scatter of 2-byte LDS writes.
 //
-// Block = 256 threads = 4 wave64s laid out WM x WN over a BM x BN tile, BK = 32,
-// LDS double-buffered with a register prefetch of the next k-tile, so there is
-// one barrier per k-step and the global loads of tile t+1 fly under the MFMAs of
-// tile t.  blockIdx.y = split-K slice, blockIdx.z = problem group (e.g. online
+// Block = 256 threads = 4 wave64s laid out WM x WN over a BM x BN tile, BK = 64
+// (two MFMA k-steps per tile), LDS double-buffered with a register prefetch of the
+// next k-tile, so there is one barrier per k-tile and the global loads of tile t+1
+// fly under the MFMAs of tile t.  LDS tiles are unpadded and XOR-swizzled so that
+// both ds_read_b128 (N mode) and ds_read_b64_tr_b16 (T mode) are bank-conflict free
+// (the first counter profile, profiles/r1_b128_counters.txt, showed 33-50 % of the LDS
+// cycles lost to conflicts with padded rows: no row padding can separate the 16-lane
+// groups ds_read_b128 is serviced in).  blockIdx.y = split-K slice, blockIdx.z = problem group (e.g. online
 // net on s0 and target net on s1 in ONE launch).
 #pragma once
 #include "common.h"
 
-#define GEMM_BK 32
+#define GEMM_BK 64          // default k-tile (elements); a template parameter of the kernel
 #define GEMM_THREADS 256
 #define GEMM_MAX_GROUPS 3
 
@@ -233,15 +237,36 @@ struct GemmGroup { SA a; SB b; EP e; int M, N, K; };
 template <class SA, class SB, class EP>
 struct GemmArgs { GemmGroup<SA, SB, EP> g[GEMM_MAX_GROUPS]; int ksplit; int tiles_n; };
 
-template <bool T, int ROWS>
-struct LdsShape {   // N mode: [ROWS][BK+8]; T mode: [BK][ROWS+8]
-    static constexpr int kPitch = T ? (ROWS + 8) : (GEMM_BK + 8);
-    static constexpr int kElems = T ? GEMM_BK * (ROWS + 8) : ROWS * (GEMM_BK + 8);
+// ---- LDS tile layouts ---------------------------------------------------------------
+// N mode: [ROWS][BK] bf16, 16-byte chunk c of row r stored at chunk position c ^ swz(r).
+//   ds_read_b128 is serviced in four 16-lane groups that mix rows {0-3,12-15} at one chunk
+//   with rows {4-11} at the neighbouring chunk; the swizzles below make every group touch 16
+//   distinct 16-byte slots of the 256-byte bank row.
+// T mode: [BK][ROWS] bf16, 8-byte chunk j of k-row kk stored at j ^ (h(kk) << 2).
+//   ds_read_b64_tr_b16 is serviced per 32-lane half = 8 k-rows x 4 chunks; h() spreads the
+//   k-rows that share banks over different 4-chunk groups.
+template <int BK>
+__device__ __forceinline__ int swz_n(int r) {
+    if (BK == 32) return (0x78 >> (2 * ((r >> 2) & 3))) & 3;       // {0,2,3,1}[(r>>2)&3]
+    int t = (r >> 1) & 7;                                            // BK == 64
+    return ((t & 1) << 1) | ((t >> 2) << 2);
+}
+template <int ROWS>
+__device__ __forceinline__ int swz_t(int kk) {
+    if (ROWS == 32) return ((kk >> 3) & 1) << 2;
+    return (((kk >> 1) & 1) | (((kk >> 3) & 1) << 1)) << 2;          // ROWS == 64
+}
+
+template <bool T, int ROWS, int BK>
+struct LdsShape {
+    static constexpr int kElems = ROWS * BK;
 };
 
-template <bool T, int ROWS, class SRC>
+template <bool T, int ROWS, int BK, class SRC>
 struct Stager {
-    static constexpr int kItems = ROWS * GEMM_BK / 8;
+    static_assert(BK == 32 || BK == 64, "k-tile of 32 or 64");
+    static_assert(ROWS == 32 || ROWS == 64, "tile side of 32 or 64");
+    static constexpr int kItems = ROWS * BK / 8;
     static constexpr int kIters = (kItems + GEMM_THREADS - 1) / GEMM_THREADS;
     typename SRC::Ctx ctx[kIters];
     int koff[kIters];
@@ -253,15 +278,15 @@ struct Stager {
         for (int i = 0; i < kIters; ++i) {
             int item = tid + i * GEMM_THREADS;
             if (!T) {
-                int r = item / (GEMM_BK / 8), kc = (item % (GEMM_BK / 8)) * 8;
+                int r = item / (BK / 8), c = item % (BK / 8);
                 ctx[i] = s.prep(row0 + r);
-                koff[i] = kc;
-                lds_off[i] = r * LdsShape<T, ROWS>::kPitch + kc;
+                koff[i] = c * 8;
+                lds_off[i] = r * BK + ((c ^ swz_n<BK>(r)) << 3);
             } else {
                 int rg = item % (ROWS / 8), kk = item / (ROWS / 8);
                 ctx[i] = s.prep(row0 + rg * 8);
                 koff[i] = kk;
-                lds_off[i] = kk * LdsShape<T, ROWS>::kPitch + rg * 8;
+                lds_off[i] = kk * ROWS + (((2 * rg) ^ swz_t<ROWS>(kk)) << 2);
             }
             if (item >= kItems) ctx[i].ok = false;
         }
@@ -277,35 +302,37 @@ struct Stager {
     }
 };
 
-// fragment for rows r0..r0+15 (lane&15), k = 8*(lane>>4) .. +7 of the current BK=32 tile
-template <bool T, int ROWS>
-__device__ __forceinline__ bf16x8 read_frag(const bf16_t* lds, int r0, int lane) {
-    constexpr int P = LdsShape<T, ROWS>::kPitch;
+// fragment for rows r0..r0+15 (lane&15), k = 32*ks + 8*(lane>>4) .. +7 of the current tile
+template <bool T, int ROWS, int BK>
+__device__ __forceinline__ bf16x8 read_frag(const bf16_t* lds, int r0, int ks, int lane) {
     if (!T) {
-        const bf16_t* p = lds + (r0 + (lane & 15)) * P + (lane >> 4) * 8;
+        int r = r0 + (lane & 15), c = ks * 4 + (lane >> 4);
+        const bf16_t* p = lds + r * BK + ((c ^ swz_n<BK>(r)) << 3);
         return *reinterpret_cast<const bf16x8*>(p);
     } else {
         // 16-lane group g reads k = 8g..8g+7 as two 4(k) x 16(row) blocks; lane 4q+p of the
         // group supplies the address of block row q, columns 4p..4p+3 and receives column
         // (lane&15) of the 4 rows.
         int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-        const bf16_t* p0 = lds + (8 * g + q) * P + r0 + 4 * pp;
+        int kk = ks * 32 + 8 * g + q, j = (r0 >> 2) + pp;
+        const bf16_t* p0 = lds + kk * ROWS + ((j ^ swz_t<ROWS>(kk)) << 2);
+        const bf16_t* p1 = lds + (kk + 4) * ROWS + ((j ^ swz_t<ROWS>(kk + 4)) << 2);
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * P));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     }
 }
 
-template <int BM, int BN, int WM, int WN, class SA, class SB, class EP>
+template <int BM, int BN, int WM, int WN, int BK, class SA, class SB, class EP>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs<SA, SB, EP> args) {
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
     static_assert(FM >= 1 && FN >= 1, "tile too small for the wave grid");
     constexpr bool TA = SA::kT, TB = SB::kT;
-    constexpr int A_ELEMS = LdsShape<TA, BM>::kElems, B_ELEMS = LdsShape<TB, BN>::kElems;
+    constexpr int A_ELEMS = LdsShape<TA, BM, BK>::kElems, B_ELEMS = LdsShape<TB, BN, BK>::kElems;
     __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (A_ELEMS + B_ELEMS)];
 
     const GemmGroup<SA, SB, EP>& G = args.g[blockIdx.z];
@@ -321,8 +348,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs<SA, SB, EP>
         if (kbeg >= kend) return;
     }
 
-    Stager<TA, BM, SA> sa;
-    Stager<TB, BN, SB> sb;
+    Stager<TA, BM, BK, SA> sa;
+    Stager<TB, BN, BK, SB> sb;
     sa.init(G.a, m0, tid);
     sb.init(G.b, n0, tid);
 
@@ -342,27 +369,30 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs<SA, SB, EP>
     sa.fetch(G.a, kbeg);
     sb.fetch(G.b, kbeg);
     int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
         bf16_t* la = lds + buf * (A_ELEMS + B_ELEMS);
         bf16_t* lb = la + A_ELEMS;
         sa.commit(la, tid);
         sb.commit(lb, tid);
         __syncthreads();
-        if (k0 + GEMM_BK < kend) {      // prefetch the next k-tile under this tile's MFMAs
-            sa.fetch(G.a, k0 + GEMM_BK);
-            sb.fetch(G.b, k0 + GEMM_BK);
+        if (k0 + BK < kend) {           // prefetch the next k-tile under this tile's MFMAs
+            sa.fetch(G.a, k0 + BK);
+            sb.fetch(G.b, k0 + BK);
         }
-        bf16x8 fa[FM], fb[FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) fa[i] = read_frag<TA, BM>(la, wm * (BM / WM) + i * 16, lane);
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 fa[FM], fb[FN];
 #pragma unroll
-        for (int j = 0; j < FN; ++j) fb[j] = read_frag<TB, BN>(lb, wn * (BN / WN) + j * 16, lane);
+            for (int i = 0; i < FM; ++i) fa[i] = read_frag<TA, BM, BK>(la, wm * (BM / WM) + i * 16, ks, lane);
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
+            for (int j = 0; j < FN; ++j) fb[j] = read_frag<TB, BN, BK>(lb, wn * (BN / WN) + j * 16, ks, lane);
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+            for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+            }
         }
         buf ^= 1;
     }
@@ -383,17 +413,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs<SA, SB, EP>
     }
 }
 
-template <int BM, int BN, int WM, int WN, class SA, class SB, class EP>
+template <int BM, int BN, int WM, int WN, class SA, class SB, class EP, int BK = GEMM_BK>
 static void launch_gemm(GemmArgs<SA, SB, EP>& args, int ngroups, int maxM, int maxN, int maxK, int ksplit,
                         hipStream_t stream) {
     int tiles_m = (maxM + BM - 1) / BM, tiles_n = (maxN + BN - 1) / BN;
     args.tiles_n = tiles_n;
     int nsplit = 1;
     if (ksplit > 0) {
-        ksplit = (ksplit + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+        ksplit = (ksplit + BK - 1) / BK * BK;
         nsplit = (maxK + ksplit - 1) / ksplit;
     }
     args.ksplit = ksplit > 0 ? ksplit : 0;
     dim3 grid(tiles_m * tiles_n, nsplit, ngroups);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, SA, SB, EP>), grid, dim3(GEMM_THREADS), 0, stream, args);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, SA, SB, EP>), grid, dim3(GEMM_THREADS), 0, stream, args);
 }

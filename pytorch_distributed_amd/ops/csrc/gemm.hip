@@ -237,6 +237,9 @@ PDA_EXPORT void pda_col2im(const void* dcol, const void* yin, void* dx, int batc
                        (const bf16_t*)yin, (bf16_t*)dx, g, batch, act);
 }
 
+// k-tile of the GEMM family: split-K slice lengths are rounded up to a multiple of this
+PDA_EXPORT int pda_gemm_bk() { return GEMM_BK; }
+
 // ---- probe: returns what ds_read_b64_tr_b16 delivers for a known LDS image (unit-tested on the GPU) --
 __global__ void tr_probe_kernel(int* out) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[32 * 72];

@@ -108,8 +108,7 @@ def _ksplit(red, tiles, target_blocks=768, minimum=64):
     """Split-K slice length (multiple of 32) so that tiles * slices ~ target_blocks."""
     slices = max(1, target_blocks // max(tiles, 1))
     ks = (red + slices - 1) // slices
-    ks = max(minimum, (ks + 31) // 32 * 32)
-    return ks
+    return nn.round_ksplit(max(minimum, ks))
 
 
 class CnnGeometry(object):

@@ -95,11 +95,29 @@ def linear_dgrad(dy, w, y, dx, M, Nout, Kin, lddy, ldw, ldy, lddx, act=ACT_NONE)
     _L().pda_linear_dgrad(_ptr(dy), _ptr(w), _ptr(y), _ptr(dx), M, Nout, Kin, lddy, ldw, ldy, lddx, act, _stream())
 
 
+_BK = None
+
+
+def gemm_bk():
+    """k-tile of the GEMM family (csrc/gemm.h GEMM_BK): the launcher rounds split-K slices up to it."""
+    global _BK
+    if _BK is None:
+        L = lib()
+        L.pda_gemm_bk.restype = ctypes.c_int
+        _BK = int(L.pda_gemm_bk())
+    return _BK
+
+
+def round_ksplit(ksplit):
+    bk = gemm_bk()
+    return (int(ksplit) + bk - 1) // bk * bk
+
+
 def num_slices(red, ksplit):
     """Split-K slices a launch with this ksplit produces over a reduction of length red."""
     if ksplit <= 0:
         return 1
-    ks = (ksplit + 31) // 32 * 32
+    ks = round_ksplit(ksplit)
     return (red + ks - 1) // ks
 
 
