@@ -27,22 +27,44 @@
 // net on s0 and target net on s1 in ONE launch).
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 #define GEMM_BK 64          // default k-tile (elements); a template parameter of the kernel
+#define GEMM_PF 3           // k-tiles of global loads kept in flight ahead of the MFMAs (register ring)
 #define GEMM_THREADS 256
-#define GEMM_MAX_GROUPS 3
+#define GEMM_MAX_GROUPS 4
 
 // ----------------------------------------------------------------------------
 // operand sources
 // ----------------------------------------------------------------------------
+// Every load is issued unconditionally (an out-of-range lane reads the tensor's first 16 bytes and
+// the value is replaced by zero afterwards): a load under a divergent branch makes the compiler fall
+// back to s_waitcnt vmcnt(0) before each LDS store, which drains the whole prefetch ring.
+// A source therefore splits a load in two: raw(ctx, k, ok) only issues it (Raw goes into the prefetch
+// ring untouched, so nothing waits on it), finish(raw, ok) masks / converts when the tile is committed
+// to LDS, GEMM_PF tiles later.
+__device__ __forceinline__ uint4 mask16(uint4 v, bool ok) {
+    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+    return v;
+}
+#define PDA_BF16_SOURCE_FINISH                                                              \
+    typedef uint4 Raw;                                                                       \
+    __device__ __forceinline__ static uint4 finish(Raw v, bool ok) { return mask16(v, ok); }
+#define PDA_U8_SOURCE_FINISH                                                                 \
+    typedef uint2 Raw;                                                                       \
+    __device__ __forceinline__ static uint4 finish(Raw v, bool ok) {                         \
+        uint2 lo = u8x4_to_bf16x4(ok ? v.x : 0u), hi = u8x4_to_bf16x4(ok ? v.y : 0u);        \
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);                                           \
+    }
 struct SrcDenseK {      // element(row, k) = p[row*ld + k]; K-contiguous
     static constexpr bool kT = false;
     const bf16_t* p; long ld; int rows; int red;
     struct Ctx { const bf16_t* base; bool ok; };
     __device__ __forceinline__ Ctx prep(int row) const { return {p + (long)row * ld, row < rows}; }
-    __device__ __forceinline__ uint4 load(const Ctx& c, int k) const {
-        if (!c.ok || k >= red) return make_uint4(0, 0, 0, 0);
-        return *reinterpret_cast<const uint4*>(c.base + k);
+    PDA_BF16_SOURCE_FINISH
+    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const {
+        ok = c.ok && k < lim;
+        return *reinterpret_cast<const uint4*>(ok ? c.base + k : p);
     }
 };
 
@@ -51,9 +73,10 @@ struct SrcDenseT {      // element(row, k) = p[k*ld + row]; row-contiguous
     const bf16_t* p; long ld; int rows; int red;
     struct Ctx { const bf16_t* base; bool ok; };
     __device__ __forceinline__ Ctx prep(int row0) const { return {p + row0, row0 < rows}; }
-    __device__ __forceinline__ uint4 load(const Ctx& c, int k) const {
-        if (!c.ok || k >= red) return make_uint4(0, 0, 0, 0);
-        return *reinterpret_cast<const uint4*>(c.base + (long)k * ld);
+    PDA_BF16_SOURCE_FINISH
+    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const {
+        ok = c.ok && k < lim;
+        return *reinterpret_cast<const uint4*>(ok ? c.base + (long)k * ld : p);
     }
 };
 
@@ -70,11 +93,12 @@ struct SrcIm2colK {
         int oy = r / g.OW, ox = r - oy * g.OW;
         return {p + (((long)b * g.H + oy * g.S) * g.W + ox * g.S) * g.C, m < rows};
     }
-    __device__ __forceinline__ uint4 load(const Ctx& c, int k) const {
-        if (!c.ok || k >= red) return make_uint4(0, 0, 0, 0);
+    PDA_BF16_SOURCE_FINISH
+    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const {
+        ok = c.ok && k < lim;
         int run = g.KW * g.C;
         int ky = k / run, off = k - ky * run;
-        return *reinterpret_cast<const uint4*>(c.base + (long)ky * g.W * g.C + off);
+        return *reinterpret_cast<const uint4*>(ok ? c.base + (long)ky * g.W * g.C + off : p);
     }
 };
 
@@ -87,13 +111,58 @@ struct SrcIm2colT {     // rows = k-columns of the im2col matrix (8 consecutive)
         int ky = kc0 / run, off = kc0 - ky * run;
         return {(long)ky * g.W * g.C + off, kc0 < rows};
     }
-    __device__ __forceinline__ uint4 load(const Ctx& c, int m) const {
-        if (!c.ok || m >= red) return make_uint4(0, 0, 0, 0);
+    PDA_BF16_SOURCE_FINISH
+    __device__ __forceinline__ Raw raw(const Ctx& c, int m, int lim, bool& ok) const {
+        ok = c.ok && m < lim;
         int ohw = g.OH * g.OW;
         int b = m / ohw, r = m - b * ohw;
         int oy = r / g.OW, ox = r - oy * g.OW;
         const bf16_t* base = p + (((long)b * g.H + oy * g.S) * g.W + ox * g.S) * g.C;
-        return *reinterpret_cast<const uint4*>(base + c.off);
+        return *reinterpret_cast<const uint4*>(ok ? base + c.off : p);
+    }
+};
+
+// ---- conv data gradient as a gather (no dcol matrix, no col2im pass) ------------------------
+// dx[b,iy,ix,c] = sum_{ky,kx,o} dy[b,(iy-ky)/S,(ix-kx)/S,o] * w[o][ky][kx][c] over the taps with
+// ky = iy mod S (+ S a), kx = ix mod S (+ S b).  Input pixels of one parity class (py,px) all use the
+// same TH x TW = (KH/S) x (KW/S) taps, so each class is one GEMM (a problem group of the launch):
+//   rows m = (b, iy2, ix2) with iy = S*iy2 + py, ix = S*ix2 + px;   k = (a, b, o);   N = C.
+struct DgradGeom { int H, W, C, O, KH, KW, S, OH, OW, HC, WC, TH, TW, py, px; };
+
+struct SrcDgradDyK {    // A operand: element(m, k) = dy[b, iy2 - a, ix2 - b, o]  (zero outside the output grid)
+    static constexpr bool kT = false;
+    const bf16_t* p; DgradGeom g; int rows; int red;
+    struct Ctx { const bf16_t* base; int iy2, ix2; bool ok; };
+    __device__ __forceinline__ Ctx prep(int m) const {
+        int hw = g.HC * g.WC;
+        bool ok = m < rows;
+        int b = ok ? m / hw : 0;
+        int r = m - b * hw;
+        int iy2 = r / g.WC, ix2 = r - iy2 * g.WC;
+        return {p + (long)b * g.OH * g.OW * g.O, iy2, ix2, ok};
+    }
+    PDA_BF16_SOURCE_FINISH
+    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const {
+        int tap = k / g.O, o = k - tap * g.O;
+        int a = tap / g.TW, bb = tap - a * g.TW;
+        int oy = c.iy2 - a, ox = c.ix2 - bb;
+        ok = c.ok && k < lim && oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW;
+        return *reinterpret_cast<const uint4*>(ok ? c.base + ((long)oy * g.OW + ox) * g.O + o : p);
+    }
+};
+
+struct SrcDgradWT {     // B operand: element(row = c, k = (a,b,o)) = w[o][(ky,kx,c)], 8 consecutive c per load
+    static constexpr bool kT = true;
+    const bf16_t* p; DgradGeom g; int rows; int red;
+    struct Ctx { const bf16_t* base; bool ok; };
+    __device__ __forceinline__ Ctx prep(int c0) const { return {p + c0, c0 < rows}; }
+    PDA_BF16_SOURCE_FINISH
+    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const {
+        ok = c.ok && k < lim;
+        int tap = k / g.O, o = k - tap * g.O;
+        int a = tap / g.TW, bb = tap - a * g.TW;
+        int ky = g.py + g.S * a, kx = g.px + g.S * bb;
+        return *reinterpret_cast<const uint4*>(ok ? c.base + ((long)o * g.KH * g.KW + ky * g.KW + kx) * g.C : p);
     }
 };
 
@@ -112,16 +181,14 @@ struct SrcFrameU8K {
         long f = idx ? (long)idx[b] : (long)b;
         return {p + f * frame_bytes + (long)(oy * g.S) * g.W + ox * g.S, ok};
     }
-    __device__ __forceinline__ uint4 load(const Ctx& c, int k) const {
-        if (!c.ok || k >= red) return make_uint4(0, 0, 0, 0);
+    PDA_U8_SOURCE_FINISH
+    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const {
+        ok = c.ok && k < lim;
         int khw = g.KH * g.KW;
         int ch = k / khw, r = k - ch * khw;
         int ky = r / g.KW;      // kx == 0: k is a multiple of 8 == KW
-        const uint8_t* src = c.base + ((long)ch * g.H + ky) * g.W;
-        uint32_t w0 = *reinterpret_cast<const uint32_t*>(src);
-        uint32_t w1 = *reinterpret_cast<const uint32_t*>(src + 4);
-        uint2 lo = u8x4_to_bf16x4(w0), hi = u8x4_to_bf16x4(w1);
-        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const uint8_t* src = ok ? c.base + ((long)ch * g.H + ky) * g.W : p;
+        return make_uint2(*reinterpret_cast<const uint32_t*>(src), *reinterpret_cast<const uint32_t*>(src + 4));
     }
 };
 
@@ -135,17 +202,16 @@ struct SrcFrameU8T {    // rows = (c, ky, kx0..kx0+7), reduction = m
         int ky = r / g.KW;
         return {((long)ch * g.H + ky) * g.W, kc0 < rows};
     }
-    __device__ __forceinline__ uint4 load(const Ctx& c, int m) const {
-        if (!c.ok || m >= red) return make_uint4(0, 0, 0, 0);
+    PDA_U8_SOURCE_FINISH
+    __device__ __forceinline__ Raw raw(const Ctx& c, int m, int lim, bool& ok) const {
+        ok = c.ok && m < lim;
+        int mm = ok ? m : 0;
         int ohw = g.OH * g.OW;
-        int b = m / ohw, r = m - b * ohw;
+        int b = mm / ohw, r = mm - b * ohw;
         int oy = r / g.OW, ox = r - oy * g.OW;
         long f = idx ? (long)idx[b] : (long)b;
-        const uint8_t* src = p + f * frame_bytes + (long)(oy * g.S) * g.W + ox * g.S + c.off;
-        uint32_t w0 = *reinterpret_cast<const uint32_t*>(src);
-        uint32_t w1 = *reinterpret_cast<const uint32_t*>(src + 4);
-        uint2 lo = u8x4_to_bf16x4(w0), hi = u8x4_to_bf16x4(w1);
-        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const uint8_t* src = ok ? p + f * frame_bytes + (long)(oy * g.S) * g.W + ox * g.S + c.off : p;
+        return make_uint2(*reinterpret_cast<const uint32_t*>(src), *reinterpret_cast<const uint32_t*>(src + 4));
     }
 };
 
@@ -202,6 +268,32 @@ struct EpiMaskBf16 {    // dgrad: out = acc * act'(y[m][n]) -> bf16 ; y is the f
                     g = (act == ACT_RELU) ? (yy > 0.f ? g : 0.f) : g * (1.f - yy * yy);
                 }
                 out[(long)(m + r) * ld + n] = f2bf(g);
+            }
+        }
+    }
+    __device__ __forceinline__ void bias_grad(int, float, int) const {}
+};
+
+// conv dgrad (gather form): row m of a parity class -> NHWC pixel row; out = acc * act'(y[pixel][n])
+struct EpiDgradScatter {
+    bf16_t* out; const bf16_t* y; int act; DgradGeom g;
+    static constexpr bool kBiasGrad = false;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N) const {
+        if (n >= N) return;
+        int hw = g.HC * g.WC;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int mm = m + r;
+            if (mm < M) {
+                int b = mm / hw, q = mm - b * hw;
+                int iy2 = q / g.WC, ix2 = q - iy2 * g.WC;
+                long pix = ((long)b * g.H + (g.S * iy2 + g.py)) * g.W + (g.S * ix2 + g.px);
+                float gr = v[r];
+                if (act != ACT_NONE) {
+                    float yy = bf2f(y[pix * g.C + n]);
+                    gr = (act == ACT_RELU) ? (yy > 0.f ? gr : 0.f) : gr * (1.f - yy * yy);
+                }
+                out[pix * g.C + n] = f2bf(gr);
             }
         }
     }
@@ -271,7 +363,8 @@ struct Stager {
     typename SRC::Ctx ctx[kIters];
     int koff[kIters];
     int lds_off[kIters];
-    uint4 reg[kIters];
+    typename SRC::Raw reg[GEMM_PF][kIters];  // ring of prefetched k-tiles (slot indices are compile-time after unrolling)
+    bool okr[GEMM_PF][kIters];
 
     __device__ __forceinline__ void init(const SRC& s, int row0, int tid) {
 #pragma unroll
@@ -291,14 +384,20 @@ struct Stager {
             if (item >= kItems) ctx[i].ok = false;
         }
     }
-    __device__ __forceinline__ void fetch(const SRC& s, int k0) {
+    // always issues kIters loads (lanes / tiles past `lim` read a dummy address and are zeroed at
+    // commit), so every path through the k-loop has the same number of loads in flight and the
+    // compiler can wait with exact vmcnt counts instead of draining the ring
+    template <int SLOT>
+    __device__ __forceinline__ void fetch(const SRC& s, int k0, int lim) {
 #pragma unroll
-        for (int i = 0; i < kIters; ++i) reg[i] = s.load(ctx[i], k0 + koff[i]);
+        for (int i = 0; i < kIters; ++i) reg[SLOT][i] = s.raw(ctx[i], k0 + koff[i], lim, okr[SLOT][i]);
     }
+    template <int SLOT>
     __device__ __forceinline__ void commit(bf16_t* lds, int tid) const {
 #pragma unroll
         for (int i = 0; i < kIters; ++i)
-            if (tid + i * GEMM_THREADS < kItems) *reinterpret_cast<uint4*>(lds + lds_off[i]) = reg[i];
+            if (kItems % GEMM_THREADS == 0 || tid + i * GEMM_THREADS < kItems)
+                *reinterpret_cast<uint4*>(lds + lds_off[i]) = SRC::finish(reg[SLOT][i], okr[SLOT][i]);
     }
 };
 
@@ -366,19 +465,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs<SA, SB, EP>
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 
-    sa.fetch(G.a, kbeg);
-    sb.fetch(G.b, kbeg);
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    // The loads of k-tiles t+1 .. t+GEMM_PF are in flight while tile t is multiplied: at batch 128 these
+    // launches are a few hundred blocks of 8-16 k-tiles, i.e. bound by memory latency, not by MFMA or
+    // LDS rate (counter profile: 58 % of wave cycles parked in s_waitcnt with one tile of prefetch).
+    auto tile = [&](auto slot_tag, int kk, int& buf) {
+        constexpr int SLOT = decltype(slot_tag)::value;
         bf16_t* la = lds + buf * (A_ELEMS + B_ELEMS);
         bf16_t* lb = la + A_ELEMS;
-        sa.commit(la, tid);
-        sb.commit(lb, tid);
+        sa.template commit<SLOT>(la, tid);
+        sb.template commit<SLOT>(lb, tid);
         __syncthreads();
-        if (k0 + BK < kend) {           // prefetch the next k-tile under this tile's MFMAs
-            sa.fetch(G.a, k0 + BK);
-            sb.fetch(G.b, k0 + BK);
-        }
+        sa.template fetch<SLOT>(G.a, kk + GEMM_PF * BK, kend);
+        sb.template fetch<SLOT>(G.b, kk + GEMM_PF * BK, kend);
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 fa[FM], fb[FN];
@@ -395,6 +493,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs<SA, SB, EP>
             }
         }
         buf ^= 1;
+    };
+    static_assert(GEMM_PF == 3, "the ring below is written out for three slots");
+    sa.template fetch<0>(G.a, kbeg, kend);
+    sb.template fetch<0>(G.b, kbeg, kend);
+    sa.template fetch<1>(G.a, kbeg + BK, kend);
+    sb.template fetch<1>(G.b, kbeg + BK, kend);
+    sa.template fetch<2>(G.a, kbeg + 2 * BK, kend);
+    sb.template fetch<2>(G.b, kbeg + 2 * BK, kend);
+    int buf = 0;
+    for (int k0 = kbeg;;) {             // straight-line body, exits only by break: no merges inside the ring
+        tile(std::integral_constant<int, 0>{}, k0, buf);
+        if (k0 + BK >= kend) break;
+        tile(std::integral_constant<int, 1>{}, k0 + BK, buf);
+        if (k0 + 2 * BK >= kend) break;
+        tile(std::integral_constant<int, 2>{}, k0 + 2 * BK, buf);
+        k0 += GEMM_PF * BK;
+        if (k0 >= kend) break;
     }
 
     // C/D layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg

@@ -95,6 +95,33 @@ PDA_EXPORT void pda_linear_dgrad(const void* dy, const void* w, const void* y, v
     else launch_gemm<64, 64, 2, 2>(a, 1, M, Kin, Nout, 0, stream);
 }
 
+// ---- conv data gradient, gather form: dx[b,iy,ix,c] (NHWC bf16) from dy (NHWC bf16) and the forward
+// weight shadow w[O][(ky,kx,c)]; times act'(y_in).  One problem group per input-pixel parity class
+// (S*S groups, S <= 2), no intermediate dcol matrix and no col2im pass.  Needs KH % S == KW % S == 0,
+// H % S == W % S == 0, O % 8 == 0, C % 8 == 0.
+PDA_EXPORT void pda_conv_dgrad(const void* dy, const void* w, const void* yin, void* dx, int batch, int H, int W,
+                               int C, int KH, int KW, int S, int O, int act, hipStream_t stream) {
+    ConvGeom cg = make_geom(H, W, C, KH, KW, S);
+    GemmArgs<SrcDgradDyK, SrcDgradWT, EpiDgradScatter> a;
+    int ng = 0, maxM = 0;
+    int K = (KH / S) * (KW / S) * O;
+    for (int py = 0; py < S; ++py)
+        for (int px = 0; px < S; ++px) {
+            DgradGeom g;
+            g.H = H; g.W = W; g.C = C; g.O = O; g.KH = KH; g.KW = KW; g.S = S; g.OH = cg.OH; g.OW = cg.OW;
+            g.HC = H / S; g.WC = W / S; g.TH = KH / S; g.TW = KW / S; g.py = py; g.px = px;
+            int M = batch * g.HC * g.WC;
+            a.g[ng].a = {(const bf16_t*)dy, g, M, K};
+            a.g[ng].b = {(const bf16_t*)w, g, C, K};
+            a.g[ng].e = {(bf16_t*)dx, (const bf16_t*)yin, yin ? act : ACT_NONE, g};
+            a.g[ng].M = M; a.g[ng].N = C; a.g[ng].K = K;
+            maxM = M > maxM ? M : maxM;
+            ++ng;
+        }
+    if (C <= 32) launch_gemm<64, 32, 4, 1>(a, ng, maxM, C, K, 0, stream);
+    else launch_gemm<64, 64, 2, 2>(a, ng, maxM, C, K, 0, stream);
+}
+
 // ---- weight gradients -----------------------------------------------------------------------------
 // All three write split-K partial tiles with plain stores in GEMM layout: slice y goes to
 // gw + y*slice_stride (+ bias column sums to gb + y*bslice_stride).  With one slice gw/gb can be

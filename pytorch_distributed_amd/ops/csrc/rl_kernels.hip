@@ -21,7 +21,7 @@ struct DqnHeadArgs {
     const float* tails; int tail_ld; int off_action, off_reward, off_gamma, off_term;
     const int* idx; const float* isw;                        // sampled replay rows, importance weights (may be null)
     bf16_t* h1_on0; bf16_t* dh1; bf16_t* dq; int dq_ld;      // outputs
-    float* q_out; float* td_out; float* loss_sum;
+    float* q_out; float* td_out; float* loss_sum;           // loss_sum: [B] per-sample accumulators
     float* leaf_sum; float* leaf_min; float prio_eps, prio_alpha;
     int B, HID, A;
     unsigned long long* rng_counter; int* opt_step;     // bumped here (nobody reads them in this launch)
@@ -50,25 +50,46 @@ __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
         if (p.h1pre_on1) p.h1pre_on1[row + j] = 0.f;
     }
 
-    // lane a keeps q(.)[a]: no runtime-indexed arrays (they would live in scratch)
+    // lane a keeps q(.)[a]: no runtime-indexed arrays (they would live in scratch).  Actions go in
+    // groups of 8 with the 24 dot products formed first and reduced together, so the shuffles of
+    // independent reductions overlap (one wave per sample = nothing else hides their latency).
     float myq0 = 0.f, myqt = 0.f, best_t = -INFINITY, best_d = -INFINITY;
     int arg_d = 0;
-    for (int a = 0; a < p.A; ++a) {
-        float s0 = 0.f, st = 0.f, sd = 0.f;
-        const float* w_on = p.w5_on + (long)a * HID + lane * PER;
-        const float* w_tg = p.w5_tg + (long)a * HID + lane * PER;
+    for (int a0 = 0; a0 < p.A; a0 += 8) {
+        float s0[8], st[8], sd[8];
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            s0 += h0[j] * w_on[j];
-            st += ht[j] * w_tg[j];
-            sd += hd[j] * w_on[j];
+        for (int u = 0; u < 8; ++u) {
+            s0[u] = 0.f; st[u] = 0.f; sd[u] = 0.f;
+            if (a0 + u < p.A) {
+                const float* w_on = p.w5_on + (long)(a0 + u) * HID + lane * PER;
+                const float* w_tg = p.w5_tg + (long)(a0 + u) * HID + lane * PER;
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    s0[u] += h0[j] * w_on[j];
+                    st[u] += ht[j] * w_tg[j];
+                    sd[u] += hd[j] * w_on[j];
+                }
+            }
         }
-        s0 = wave_sum(s0) + p.b5_on[a];
-        st = wave_sum(st) + p.b5_tg[a];
-        sd = wave_sum(sd) + p.b5_on[a];
-        if (lane == a) { myq0 = s0; myqt = st; }
-        best_t = fmaxf(best_t, st);
-        if (sd > best_d) { best_d = sd; arg_d = a; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s0[u] += __shfl_xor(s0[u], o, 64);
+                st[u] += __shfl_xor(st[u], o, 64);
+                sd[u] += __shfl_xor(sd[u], o, 64);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int a = a0 + u;
+            if (a < p.A) {
+                float q0 = s0[u] + p.b5_on[a], qt = st[u] + p.b5_tg[a], qd = sd[u] + p.b5_on[a];
+                if (lane == a) { myq0 = q0; myqt = qt; }
+                best_t = fmaxf(best_t, qt);
+                if (qd > best_d) { best_d = qd; arg_d = a; }
+            }
+        }
     }
     float next_q = p.h1pre_on1 ? __shfl(myqt, arg_d, 64) : best_t;
 
@@ -97,7 +118,9 @@ __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
     if (lane < p.A && p.q_out) p.q_out[(long)b * p.A + lane] = myq0;
     if (lane == 0) {
         if (p.td_out) p.td_out[b] = td;
-        atomicAdd(p.loss_sum, w * td * td / (float)p.B);
+        // per-sample loss accumulator (summed on the host side when the logger asks): 128 fp32
+        // atomics on one address serialise memory-side and were half of this kernel's time
+        p.loss_sum[b] += w * td * td / (float)p.B;
         if (p.leaf_sum) {
             float leaf = __powf(fabsf(td) + p.prio_eps, p.prio_alpha);
             p.leaf_sum[ridx] = leaf;
@@ -231,13 +254,23 @@ __device__ __forceinline__ long master_index(const SegEntry& s, int j, long* sha
     return (long)s.start + (long)row * s.cols + c * s.P + pp;
 }
 
-#define OPT_CHUNK 2048      // elements per block
+#define OPT_CHUNK 2048      // elements per block (flat chunks)
+#define OPT_ROW_LDS 4352    // floats of LDS for one weight row in the transposition path (row pitch padded to odd)
+
+// A chunk is (segment, first element).  Segments whose master layout is a per-row transpose of the
+// kernel layout (C > 1: conv2/conv3/fc1 weights) are chunked one ROW per block when the row fits in
+// LDS; everything else in flat OPT_CHUNK pieces.  (ops/optim.py:SegmentTable builds the list.)
+__device__ __forceinline__ bool row_mode(const SegEntry& s) {
+    return (s.flags & 1) && s.C > 1 && (s.P | 1) * s.C <= OPT_ROW_LDS;
+}
+__device__ __forceinline__ int chunk_len(const SegEntry& s) { return row_mode(s) ? s.cols : OPT_CHUNK; }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16_t* __restrict__ shadow, const SegEntry* __restrict__ segs,
                                                    const int2* __restrict__ chunks, const float* __restrict__ hyper,
                                                    const int* __restrict__ step) {
+    __shared__ float row[OPT_ROW_LDS];
     int2 ch = chunks[blockIdx.x];           // (segment, first element within the segment)
     SegEntry s = segs[ch.x];
     float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], clip = hyper[5],
@@ -245,6 +278,42 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     float t = (float)max(*step, 1);
     float bc1 = 1.f - __powf(b1, t), bc2 = 1.f - __powf(b2, t);
     float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+    if (row_mode(s)) {
+        // One weight row.  The fp32 master keeps PyTorch's [c][p] order, gradients / moments / bf16 shadow
+        // the kernels' [p][c] order.  Walking kernel order against the master directly costs one 64-byte
+        // sector per 4-byte access (24 us for the 1.6 M fc1 weights); here the master row crosses LDS:
+        // coalesced in, transposed access in LDS (the pitch P, padded to odd, spreads the banks),
+        // coalesced out.
+        int r = ch.y / s.cols;
+        float* prow = p + (long)s.start + (long)r * s.cols;
+        int P = s.P, C = s.C, pitch = P | 1;
+        for (int i = threadIdx.x; i < s.cols; i += 256) {
+            int c = i / P, pp = i - c * P;
+            row[c * pitch + pp] = prow[i];
+        }
+        __syncthreads();
+        long gbase = (long)s.start + (long)r * s.cols;
+        long sbase = (long)s.shadow_off + (long)r * s.shadow_ld;
+        for (int q = threadIdx.x; q < s.cols; q += 256) {   // q = pp * C + c (kernel order)
+            int pp = q / C, c = q - pp * C;
+            long i = gbase + q;
+            float gi = g[i] * gscale;
+            gi = fminf(fmaxf(gi, -clip), clip);
+            float pi = row[c * pitch + pp];
+            gi += wd * pi;
+            float mi = b1 * m[i] + (1.f - b1) * gi;
+            float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+            pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+            row[c * pitch + pp] = pi; m[i] = mi; v[i] = vi;
+            shadow[sbase + q] = f2bf(pi);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < s.cols; i += 256) {
+            int c = i / P, pp = i - c * P;
+            prow[i] = row[c * pitch + pp];
+        }
+        return;
+    }
     int end = min(ch.y + OPT_CHUNK, s.count);
     for (int e = ch.y + threadIdx.x; e < end; e += 256) {
         long si;
@@ -285,7 +354,7 @@ __global__ __launch_bounds__(256) void polyak_kernel(float* tgt, const float* sr
                                                      const int2* __restrict__ chunks, float tau) {
     int2 ch = chunks[blockIdx.x];
     SegEntry s = segs[ch.x];
-    int end = min(ch.y + OPT_CHUNK, s.count);
+    int end = min(ch.y + chunk_len(s), s.count);
     for (int e = ch.y + threadIdx.x; e < end; e += 256) {
         long si;
         long i = master_index(s, e, &si);

@@ -212,10 +212,17 @@ class _Acts(object):
             self.dq_ld = max(16, (g.A + 7) // 8 * 8)
             self.dq = z(B, self.dq_ld)
             self.da3 = z(B * g.P3, 64)
-            self.dcol3 = z(B * g.P3, g.K3)
             self.da2 = z(B * g.H2 * g.W2, 64)
-            self.dcol2 = z(B * g.H2 * g.W2, g.K2)
             self.da1 = z(B * g.H1 * g.W1, 32)
+            # gather-form data gradients need no dcol matrices; odd layer geometries fall back to
+            # dcol GEMM + col2im
+            # (measured on MI355X: the gather form is ~4 % slower end to end at batch 128 and 4096 --
+            # 4-9 latency-bound k-tiles against one output-bound tile + a bandwidth pass -- so it is
+            # opt-in; it saves the dcol buffers: 0.9 GB at batch 4096)
+            self.fused_dgrad = g.H1 % 2 == 0 and g.W1 % 2 == 0 and os.environ.get("PDA_FUSED_DGRAD", "0") == "1"
+            if not self.fused_dgrad:
+                self.dcol3 = z(B * g.P3, g.K3)
+                self.dcol2 = z(B * g.H2 * g.W2, g.K2)
 
 
 def cnn_forward(geom, nets, frames, idxs, acts, B, norm_val):
@@ -258,7 +265,7 @@ class DqnCnnEngine(object):
         self.uniforms = torch.zeros(self.B, dtype=torch.float32, device=dev)
         self.td = torch.zeros(self.B, dtype=torch.float32, device=dev)
         self.q = torch.zeros(self.B, g.A, dtype=torch.float32, device=dev)
-        self.loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.loss_acc = torch.zeros(self.B, dtype=torch.float32, device=dev)     # per-sample sums (no atomics)
         self.loss_steps = 0
         self.size_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -268,6 +275,13 @@ class DqnCnnEngine(object):
         self.step_count = 0
         # the tail bucket [fc1.weight .. end] is ready right after the two fc wgrads
         self.tail_start = self.online.off["critic.1.0"][0]
+        # weight gradients run on a side stream beside the data-gradient chain (a forked branch of the
+        # step's hipGraph): at batch 128 every kernel fills a fraction of the chip, so the branch is free
+        self.side = torch.cuda.Stream(device=dev)
+        self.ev_fork, self.ev_da3, self.ev_da2, self.ev_side = (torch.cuda.Event() for _ in range(4))
+        # (measured: 4828 vs 5240 updates/s -- cross-stream edges inside a hipGraph cost more than the
+        # overlap returns on this runtime, so the branch is off unless asked for)
+        self.overlap_wgrad = os.environ.get("PDA_OVERLAP_WGRAD", "0") == "1"
         polyak_(self.target.flat, self.online.flat, 1.0, self.target.table, self.target.shadow)   # hard copy to start
 
     def _plan_wgrads(self):
@@ -361,17 +375,37 @@ class DqnCnnEngine(object):
         on = self.online
         M3, M2 = B * g.P3, B * g.H2 * g.W2
         (w1s, b1s, ks1, st1, bst1), (w2s, b2s, ks2, st2, bst2), (w3s, b3s, ks3, st3, bst3) = self.wg_slabs
+        cur, side, fork = torch.cuda.current_stream(), self.side, self.overlap_wgrad
+
+        def on_side(ready, fn):
+            """fn() on the side stream once `ready` (recorded here on the main stream) has passed."""
+            if not fork:
+                return fn()
+            ready.record(cur)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                fn()
+
         nn.linear_dgrad(a.dh1, on.w[3], a.a3[0], a.da3, B, g.HID, g.F, g.HID, g.F, g.F, g.F, act=nn.ACT_RELU)
-        nn.conv_wgrad(a.da3, a.a2[0], w3s, b3s, B, g.H2, g.W2, 64, 3, 3, 1, 64, ksplit=ks3, slice_stride=st3,
-                      bslice_stride=bst3)
-        nn.linear_dgrad(a.da3, on.w[2], None, a.dcol3, M3, 64, g.K3, 64, g.K3, 0, g.K3)
-        nn.col2im(a.dcol3, a.a2[0], a.da2, B, g.H2, g.W2, 64, 3, 3, 1, act=nn.ACT_RELU)
-        nn.conv_wgrad(a.da2, a.a1[0], w2s, b2s, B, g.H1, g.W1, 32, 4, 4, 2, 64, ksplit=ks2, slice_stride=st2,
-                      bslice_stride=bst2)
-        nn.linear_dgrad(a.da2, on.w[1], None, a.dcol2, M2, 64, g.K2, 64, g.K2, 0, g.K2)
-        nn.col2im(a.dcol2, a.a1[0], a.da1, B, g.H1, g.W1, 32, 4, 4, 2, act=nn.ACT_RELU)
+        on_side(self.ev_da3, lambda: nn.conv_wgrad(a.da3, a.a2[0], w3s, b3s, B, g.H2, g.W2, 64, 3, 3, 1, 64,
+                                                   ksplit=ks3, slice_stride=st3, bslice_stride=bst3))
+        if a.fused_dgrad:
+            nn.conv_dgrad(a.da3, on.w[2], a.a2[0], a.da2, B, g.H2, g.W2, 64, 3, 3, 1, 64, act=nn.ACT_RELU)
+        else:
+            nn.linear_dgrad(a.da3, on.w[2], None, a.dcol3, M3, 64, g.K3, 64, g.K3, 0, g.K3)
+            nn.col2im(a.dcol3, a.a2[0], a.da2, B, g.H2, g.W2, 64, 3, 3, 1, act=nn.ACT_RELU)
+        on_side(self.ev_da2, lambda: nn.conv_wgrad(a.da2, a.a1[0], w2s, b2s, B, g.H1, g.W1, 32, 4, 4, 2, 64,
+                                                   ksplit=ks2, slice_stride=st2, bslice_stride=bst2))
+        if a.fused_dgrad:
+            nn.conv_dgrad(a.da2, on.w[1], a.a1[0], a.da1, B, g.H1, g.W1, 32, 4, 4, 2, 64, act=nn.ACT_RELU)
+        else:
+            nn.linear_dgrad(a.da2, on.w[1], None, a.dcol2, M2, 64, g.K2, 64, g.K2, 0, g.K2)
+            nn.col2im(a.dcol2, a.a1[0], a.da1, B, g.H1, g.W1, 32, 4, 4, 2, act=nn.ACT_RELU)
         nn.conv_wgrad_u8(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / self.norm_val,
                          ksplit=ks1, slice_stride=st1, bslice_stride=bst1)
+        if fork:                # join: everything queued on the side stream (incl. fc wgrads put there by the caller)
+            self.ev_side.record(side)
+            cur.wait_event(self.ev_side)
         self.reduce.run()
 
     def grads_torch_layout(self):
@@ -400,7 +434,7 @@ class DqnCnnEngine(object):
     def mean_loss(self):
         """Mean loss since the last call (one host sync)."""
         n = max(self.loss_steps, 1)
-        val = float(self.loss_acc.item()) / n
+        val = float(self.loss_acc.sum().item()) / n
         self.loss_acc.zero_()
         self.loss_steps = 0
         return val
@@ -455,7 +489,24 @@ class DqnStepProgram(object):
             self.e.update(self.staged)
 
     def _whole(self):
-        self._part_a()
+        e = self.e
+        if not e.overlap_wgrad:
+            self._part_a()
+            self._part_b()
+            self._part_c()
+            return
+        # single rank: the two fc weight gradients also leave the critical path (the side stream is
+        # joined inside backward_conv, before the split-K reduce)
+        if not self.staged:
+            with _Range("learner/sample"):
+                e.sample()
+        with _Range("learner/forward+td_head"):
+            e.forward_head(self.staged)
+        cur = torch.cuda.current_stream()
+        e.ev_fork.record(cur)
+        with torch.cuda.stream(e.side):
+            e.side.wait_event(e.ev_fork)
+            e.backward_fc()
         self._part_b()
         self._part_c()
 

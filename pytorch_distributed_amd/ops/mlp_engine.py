@@ -161,13 +161,15 @@ class MlpWeights(object):
 class _EngineBase(object):
     """Sampling state, replay binding and bookkeeping shared by the two MLP engines."""
 
-    def _init_common(self, B, dev, per, seed, tail_offsets, n_losses):
+    def _init_common(self, B, dev, per, seed, tail_offsets, n_losses, per_sample_loss=False):
         self.B, self.device, self.per = int(B), dev, per
         self.idx = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self.isw = torch.ones(self.B, dtype=torch.float32, device=dev)
         self.uniforms = torch.zeros(self.B, dtype=torch.float32, device=dev)
         self.td = torch.zeros(self.B, dtype=torch.float32, device=dev)
-        self.loss_acc = torch.zeros(n_losses, dtype=torch.float32, device=dev)
+        # pda_dqn_head accumulates its loss per sample (no atomics): one slot per batch row
+        self.per_sample_loss = per_sample_loss
+        self.loss_acc = torch.zeros(self.B if per_sample_loss else n_losses, dtype=torch.float32, device=dev)
         self.loss_steps = 0
         self.size_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -214,7 +216,7 @@ class _EngineBase(object):
 
     def mean_losses(self):
         n = max(self.loss_steps, 1)
-        vals = (self.loss_acc / n).tolist()
+        vals = [float(self.loss_acc.sum()) / n] if self.per_sample_loss else (self.loss_acc / n).tolist()
         self.loss_acc.zero_()
         self.loss_steps = 0
         return vals
@@ -363,7 +365,7 @@ class DqnMlpEngine(_EngineBase):
         self.A = on.shape["critic.6"][0]
         if self.HID not in HID_SUPPORTED or self.A > 64:
             raise ValueError("unsupported dqn-mlp head shape")
-        self._init_common(batch_size, dev, per, seed, tail_offsets, n_losses=1)
+        self._init_common(batch_size, dev, per, seed, tail_offsets, n_losses=1, per_sample_loss=True)
         self.norm_val = float(model.norm_val)
         self.double = bool(double)
         self.target_update = target_update

@@ -53,6 +53,8 @@ def _L():
         L.pda_conv_wgrad_u8.argtypes = [_vp] * 5 + [c_int] * 8 + [c_float, c_long, c_long, c_int, _vp]
         L.pda_wgrad_reduce.argtypes = [_vp] * 5 + [c_int, _vp]
         L.pda_col2im.argtypes = [_vp] * 3 + [c_int] * 8 + [_vp]
+        L.pda_conv_dgrad.argtypes = [_vp] * 4 + [c_int] * 9 + [_vp]
+        L.pda_conv_dgrad.restype = None
         L.pda_tr_probe.argtypes = [_vp, _vp]
         for name in ("pda_conv_fwd_u8", "pda_conv_fwd", "pda_linear_fwd", "pda_linear_dgrad", "pda_linear_wgrad",
                      "pda_conv_wgrad", "pda_conv_wgrad_u8", "pda_col2im", "pda_tr_probe", "pda_wgrad_reduce"):
@@ -161,6 +163,13 @@ class ReducePlan(object):
 
     def run(self):
         _L().pda_wgrad_reduce(self.slabs, self.dsts, self.counts, self.nslices, self.strides, self.n, _stream())
+
+
+def conv_dgrad(dy, w, yin, dx, batch, H, W, C, KH, KW, S, O, act=ACT_RELU):
+    """dx[(b,iy,ix)][c] = conv data gradient of dy[(b,oy,ox)][o] through w[O][(ky,kx,c)], times act'(yin):
+    a gather-form implicit GEMM per input-pixel parity class -- no dcol matrix, no col2im pass."""
+    assert S in (1, 2) and KH % S == 0 and KW % S == 0 and H % S == 0 and W % S == 0 and C % 8 == 0 and O % 8 == 0
+    _L().pda_conv_dgrad(_ptr(dy), _ptr(w), _ptr(yin), _ptr(dx), batch, H, W, C, KH, KW, S, O, act, _stream())
 
 
 def col2im(dcol, yin, dx, batch, H, W, C, KH, KW, S, act=ACT_RELU):

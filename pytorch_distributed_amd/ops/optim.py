@@ -16,6 +16,7 @@ import torch
 from . import lib
 
 OPT_CHUNK = 2048
+OPT_ROW_LDS = 4352      # csrc/rl_kernels.hip: LDS floats for one weight row in the transposition path
 _vp = ctypes.c_void_p
 
 
@@ -37,7 +38,9 @@ class SegmentTable(object):
             rows.append([e["start"], e["count"], e.get("cols", e["count"]), e.get("C", 1),
                          e.get("P", e.get("cols", e["count"])), e.get("shadow_off", 0), e.get("shadow_ld", 0),
                          1 if e.get("shadow", False) else 0])
-            for first in range(0, e["count"], OPT_CHUNK):
+            cols, C, P = rows[-1][2], rows[-1][3], rows[-1][4]
+            row_mode = bool(e.get("shadow", False)) and C > 1 and (P | 1) * C <= OPT_ROW_LDS
+            for first in range(0, e["count"], cols if row_mode else OPT_CHUNK):     # one row per block | flat chunks
                 chunks.append([si, first])
         self.segs = torch.tensor(rows, dtype=torch.int32).to(device)
         self.chunks = torch.tensor(chunks, dtype=torch.int32).to(device)

@@ -159,6 +159,11 @@ def test_conv_backward_nhwc(nn, geom):
     dx = torch.zeros(batch * H * W, C, dtype=torch.bfloat16, device="cuda")
     nn.col2im(dcol, nn.nhwc(x.detach()), dx, batch, H, W, C, KH, KW, S, act=nn.ACT_RELU)
     close(nn.from_nhwc(dx, batch, H, W, C), x.grad * (x.detach() > 0), 3e-2, 3e-2)
+    # the fused gather-form data gradient gives the same thing in one launch
+    dx2 = torch.full((batch * H * W, C), 9.0, dtype=torch.bfloat16, device="cuda")
+    nn.conv_dgrad(nn.nhwc(dy), nn.pack_conv_weight(w), nn.nhwc(x.detach()), dx2, batch, H, W, C, KH, KW, S, O,
+                  act=nn.ACT_RELU)
+    close(nn.from_nhwc(dx2, batch, H, W, C), x.grad * (x.detach() > 0), 3e-2, 3e-2)
 
 
 def test_conv1_wgrad_u8(nn):

@@ -241,7 +241,7 @@ def test_dqn_mlp_forward_backward_matches_torch(eng, double):
     loss = ((qall.gather(1, a.long()) - y) ** 2).mean()
     loss.backward()
     assert rel_err(e.q, qall.detach()) < 2e-2
-    assert abs(e.loss_acc.item() - loss.item()) < 3e-2 * max(1.0, loss.item())
+    assert abs(e.loss_acc.sum().item() - loss.item()) < 3e-2 * max(1.0, loss.item())
     off, errs = 0, {}
     for name, p in ref.named_parameters():
         got = e.grads[off:off + p.numel()].view_as(p)
