@@ -139,6 +139,24 @@ PDA_EXPORT void pda_linear_wgrad(const void* dy, const void* x, void* gw, void* 
     else launch_gemm<64, 64, 2, 2>(a, 1, Nout, Kin, B, ksplit, stream);
 }
 
+// two linear weight gradients over the same batch in ONE launch (problem groups; single slice each):
+// at batch 128 the fc2 gradient is a 4 us launch of its own for a few kFLOP
+PDA_EXPORT void pda_linear_wgrad2(const void* const* dy, const void* const* x, void* const* gw, void* const* gb,
+                                  int B, const int* Nout, const int* Kin, const long* lddy, const long* ldx,
+                                  const long* ldg, hipStream_t stream) {
+    GemmArgs<SrcDenseT, SrcDenseT, EpiWgrad> a;
+    int maxM = 0, maxN = 0;
+    for (int i = 0; i < 2; ++i) {
+        a.g[i].a = {(const bf16_t*)dy[i], lddy[i], Nout[i], B};
+        a.g[i].b = {(const bf16_t*)x[i], ldx[i], Kin[i], B};
+        a.g[i].e = {(float*)gw[i], (float*)gb[i], ldg[i], 0, 0, 1.f};
+        a.g[i].M = Nout[i]; a.g[i].N = Kin[i]; a.g[i].K = B;
+        maxM = Nout[i] > maxM ? Nout[i] : maxM;
+        maxN = Kin[i] > maxN ? Kin[i] : maxN;
+    }
+    launch_gemm<64, 64, 2, 2>(a, 2, maxM, maxN, B, 0, stream);
+}
+
 // conv, NHWC bf16 input: gw[O][(ky,kx,c)] = sum_m dy[m][o] * im2col(x)[m][k]
 PDA_EXPORT void pda_conv_wgrad(const void* dy, const void* x, void* gw, void* gb, int batch, int H, int W, int C,
                                int KH, int KW, int S, int O, long slice_stride, long bslice_stride, int ksplit,

@@ -254,6 +254,17 @@ __device__ __forceinline__ long master_index(const SegEntry& s, int j, long* sha
     return (long)s.start + (long)row * s.cols + c * s.P + pp;
 }
 
+// Optional work folded into the optimizer launch (each saves a ~4-8 us kernel of the 20-kernel step):
+//   * split-K gradient slabs are summed here instead of by wgrad_reduce_kernel (single-rank steps;
+//     a data-parallel step needs the reduced gradient before the all-reduce and keeps the reduce launch)
+//   * the uniform replay indices of the NEXT step are drawn by extra blocks of this launch: every
+//     consumer of the current indices has finished by now, and the rng counter was bumped by the head
+struct AdamExtras {
+    const float* slab; const int4* slabinfo;        // per segment (slab_off, nslices, slice_stride, -)
+    int* next_idx; float* next_w; int next_B; const int* size; unsigned long long seed;
+    const unsigned long long* counter;
+};
+
 #define OPT_CHUNK 2048      // elements per block (flat chunks)
 #define OPT_ROW_LDS 4352    // floats of LDS for one weight row in the transposition path (row pitch padded to odd)
 
@@ -263,14 +274,50 @@ __device__ __forceinline__ long master_index(const SegEntry& s, int j, long* sha
 __device__ __forceinline__ bool row_mode(const SegEntry& s) {
     return (s.flags & 1) && s.C > 1 && (s.P | 1) * s.C <= OPT_ROW_LDS;
 }
-__device__ __forceinline__ int chunk_len(const SegEntry& s) { return row_mode(s) ? s.cols : OPT_CHUNK; }
+// flags bit 1: "fine" flat chunks of one element per thread (segments whose gradient is summed from
+// many split-K slabs inside the optimizer: the slice loop must not also serialise over elements)
+__device__ __forceinline__ int chunk_len(const SegEntry& s) {
+    return row_mode(s) ? s.cols : ((s.flags & 2) ? 256 : OPT_CHUNK);
+}
+
+// gradient element e (kernel order within segment seg): the flat buffer, or the sum of the split-K slabs
+__device__ __forceinline__ float grad_at(const AdamExtras& x, int seg, int e, float* g, long i) {
+    if (x.slab == nullptr) return g[i];
+    int4 si = x.slabinfo[seg];
+    if (si.y <= 0) return g[i];
+    const float* q = x.slab + si.x + e;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int sl = 0;
+    for (; sl + 4 <= si.y; sl += 4) {
+        a0 += q[(long)sl * si.z];
+        a1 += q[(long)(sl + 1) * si.z];
+        a2 += q[(long)(sl + 2) * si.z];
+        a3 += q[(long)(sl + 3) * si.z];
+    }
+    for (; sl < si.y; ++sl) a0 += q[(long)sl * si.z];
+    float gi = (a0 + a1) + (a2 + a3);
+    g[i] = gi;          // keep the flat gradient readable (tests, debugging)
+    return gi;
+}
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16_t* __restrict__ shadow, const SegEntry* __restrict__ segs,
-                                                   const int2* __restrict__ chunks, const float* __restrict__ hyper,
-                                                   const int* __restrict__ step) {
+                                                   const int2* __restrict__ chunks, int nchunks,
+                                                   const float* __restrict__ hyper,
+                                                   const int* __restrict__ step, AdamExtras x) {
     __shared__ float row[OPT_ROW_LDS];
+    if ((int)blockIdx.x >= nchunks) {       // sampler blocks (only launched when x.next_idx is set)
+        int i = ((int)blockIdx.x - nchunks) * 256 + threadIdx.x;
+        if (i < x.next_B) {
+            unsigned long long ctr = *x.counter;
+            int n = max(*x.size, 1);
+            uint32_t r = hash_u32(x.seed ^ (ctr * 0x9e3779b97f4a7c15ULL + (unsigned long long)i + 1));
+            x.next_idx[i] = (int)(((unsigned long long)r * (unsigned long long)n) >> 32);
+            if (x.next_w) x.next_w[i] = 1.f;
+        }
+        return;
+    }
     int2 ch = chunks[blockIdx.x];           // (segment, first element within the segment)
     SegEntry s = segs[ch.x];
     float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], clip = hyper[5],
@@ -297,7 +344,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         for (int q = threadIdx.x; q < s.cols; q += 256) {   // q = pp * C + c (kernel order)
             int pp = q / C, c = q - pp * C;
             long i = gbase + q;
-            float gi = g[i] * gscale;
+            float gi = grad_at(x, ch.x, r * s.cols + q, g, i) * gscale;
             gi = fminf(fmaxf(gi, -clip), clip);
             float pi = row[c * pitch + pp];
             gi += wd * pi;
@@ -314,12 +361,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         }
         return;
     }
-    int end = min(ch.y + OPT_CHUNK, s.count);
+    int end = min(ch.y + chunk_len(s), s.count);
     for (int e = ch.y + threadIdx.x; e < end; e += 256) {
         long si;
         long ip = master_index(s, e, &si);
         long i = (long)s.start + e;
-        float gi = g[i] * gscale;
+        float gi = grad_at(x, ch.x, e, g, i) * gscale;
         gi = fminf(fmaxf(gi, -clip), clip);
         float pi = p[ip];
         gi += wd * pi;
@@ -343,9 +390,19 @@ PDA_EXPORT void pda_tick(void* step, void* counter, hipStream_t stream) {
 
 PDA_EXPORT void pda_adam(void* p, void* g, void* m, void* v, void* shadow, const void* segs, const void* chunks,
                          int nchunks, const void* hyper, void* step, hipStream_t stream) {
+    AdamExtras x = {};
     hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, stream, (float*)p, (float*)g, (float*)m, (float*)v,
-                       (bf16_t*)shadow, (const SegEntry*)segs, (const int2*)chunks, (const float*)hyper,
-                       (const int*)step);
+                       (bf16_t*)shadow, (const SegEntry*)segs, (const int2*)chunks, nchunks, (const float*)hyper,
+                       (const int*)step, x);
+}
+// same, with the folded-in slab reduction and/or next-step sampler (AdamExtras above)
+PDA_EXPORT void pda_adam_x(void* p, void* g, void* m, void* v, void* shadow, const void* segs, const void* chunks,
+                           int nchunks, const void* hyper, void* step, const AdamExtras* extras, hipStream_t stream) {
+    AdamExtras x = *extras;
+    int extra_blocks = x.next_idx ? (x.next_B + 255) / 256 : 0;
+    hipLaunchKernelGGL(adam_kernel, dim3(nchunks + extra_blocks), dim3(256), 0, stream, (float*)p, (float*)g,
+                       (float*)m, (float*)v, (bf16_t*)shadow, (const SegEntry*)segs, (const int2*)chunks, nchunks,
+                       (const float*)hyper, (const int*)step, x);
 }
 
 // tgt = (1 - tau) tgt + tau src (tau >= 1: hard copy) on fp32 masters, with the target's shadow weights

@@ -32,7 +32,7 @@ import numpy as np
 import torch
 
 from . import lib, nn
-from .optim import FlatAdam, SegmentTable, polyak_
+from .optim import AdamExtras, FlatAdam, SegmentTable, polyak_
 
 _vp = ctypes.c_void_p
 BF16 = torch.bfloat16
@@ -150,7 +150,8 @@ class CnnWeights(object):
             boff, bshape = segs[layer + ".bias"]
             wn, bn = int(np.prod(wshape)), int(np.prod(bshape))
             self.off[layer] = (woff, wn, boff, bn)
-            ent = {"start": woff, "count": wn, "cols": wn // wshape[0]}
+            # conv gradients arrive as split-K slabs that the optimizer may sum itself: one element per thread
+            ent = {"start": woff, "count": wn, "cols": wn // wshape[0], "fine": li < 3}
             if li < 4:
                 rows, cols, C, P = shadow_shapes[li]
                 assert rows == wshape[0] and cols == wn // wshape[0], (layer, wshape, rows, cols)
@@ -160,7 +161,7 @@ class CnnWeights(object):
             else:
                 self.w.append(self.flat[woff:woff + wn].view(wshape))       # fc2 stays fp32
             entries.append(ent)
-            entries.append({"start": boff, "count": bn})
+            entries.append({"start": boff, "count": bn, "fine": li < 3})
             self.b.append(self.flat[boff:boff + bn])
         self.table = SegmentTable(entries, dev)
         self.refresh()
@@ -260,6 +261,7 @@ class DqnCnnEngine(object):
         self.groups = 3 if self.double else 2
         self.acts = _Acts(g, self.B, self.groups, dev, backward=True)
         self._plan_wgrads()
+        self._fc_pair = None
         self.idx = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self.isw = torch.ones(self.B, dtype=torch.float32, device=dev)
         self.uniforms = torch.zeros(self.B, dtype=torch.float32, device=dev)
@@ -308,6 +310,15 @@ class DqnCnnEngine(object):
             jobs.append((w, self.gw[li], O * K, ns, O * K))
             jobs.append((b, self.gb[li], O, ns, O))
         self.reduce = nn.ReducePlan(jobs)
+        # the same sums, folded into the optimizer launch (single-rank steps): per parameter segment
+        # (weight li -> segment 2*li, bias -> 2*li + 1) where its split-K slab starts and how many slices
+        info = torch.zeros(2 * len(self.online.ORDER), 4, dtype=torch.int32)
+        base = self.slab.data_ptr()
+        for li, O, K, ks, ns in plans:
+            w, b, _, wstride, bstride = self.wg_slabs[li]
+            info[2 * li] = torch.tensor([(w.data_ptr() - base) // 4, ns, wstride, 0], dtype=torch.int32)
+            info[2 * li + 1] = torch.tensor([(b.data_ptr() - base) // 4, ns, bstride, 0], dtype=torch.int32)
+        self.slabinfo = info.to(dev)
 
     # ---- data sources --------------------------------------------------------------------------
     def bind_replay(self, state0s, state1s, tails, tree=None):
@@ -365,11 +376,27 @@ class DqnCnnEngine(object):
 
     def backward_fc(self):
         g, B, a = self.geom, self.B, self.acts
-        # one slice each: written straight into the gradient buffer (kernel layout)
-        nn.linear_wgrad(a.dq, a.h1, self.gw[4], self.gb[4], B, g.A, g.HID, a.dq_ld, g.HID, g.HID)
-        nn.linear_wgrad(a.dh1, a.a3[0], self.gw[3], self.gb[3], B, g.HID, g.F, g.HID, g.F, g.F)
+        # one slice each, written straight into the gradient buffer (kernel layout); both in one launch
+        if self._fc_pair is None:
+            self._fc_pair = nn.LinearWgradPair(
+                [(a.dh1, a.a3[0], self.gw[3], self.gb[3], g.HID, g.F, g.HID, g.F, g.F),
+                 (a.dq, a.h1, self.gw[4], self.gb[4], g.A, g.HID, a.dq_ld, g.HID, g.HID)], B)
+        self._fc_pair.run()
 
-    def backward_conv(self, staged=False):
+    def fused_extras(self, staged):
+        """AdamExtras for a single-rank step: slab sums in the optimizer launch, plus (device replay,
+        uniform sampling) the draw of the next step's replay indices."""
+        x = AdamExtras()
+        x.slab, x.slabinfo = self.slab.data_ptr(), self.slabinfo.data_ptr()
+        if self.presamples(staged):
+            x.next_idx, x.next_w, x.next_B = self.idx.data_ptr(), self.isw.data_ptr(), self.B
+            x.size, x.seed, x.counter = self.size_dev.data_ptr(), self.seed, self.counter.data_ptr()
+        return x
+
+    def presamples(self, staged):
+        return (not staged) and self.replay is not None and not (self.replay[3] is not None and self.per is not None)
+
+    def backward_conv(self, staged=False, reduce=True):
         g, B, a = self.geom, self.B, self.acts
         s0, _, _, idx, _ = self._sources(staged)
         on = self.online
@@ -406,15 +433,16 @@ class DqnCnnEngine(object):
         if fork:                # join: everything queued on the side stream (incl. fc wgrads put there by the caller)
             self.ev_side.record(side)
             cur.wait_event(self.ev_side)
-        self.reduce.run()
+        if reduce:
+            self.reduce.run()
 
     def grads_torch_layout(self):
         """The flat gradient re-ordered to PyTorch's parameter layout (tests, debugging)."""
         return self.online.to_torch_layout(self.grads)
 
-    def update(self, staged=False, tick=False):
+    def update(self, staged=False, tick=False, extras=None):
         """tick: bump Adam's step counter here (the head kernel does it in a full step)."""
-        self.adam.step(tick=tick)
+        self.adam.step(tick=tick, extras=extras)
         self.post_update(staged)
 
     def post_update(self, staged=False):
@@ -459,6 +487,9 @@ class DqnStepProgram(object):
         self.graphs = None
         self.dp_graph_mode = None
         self.calls = 0
+        self.fused_tail = (not self.dp) and os.environ.get("PDA_FUSED_TAIL", "1") != "0"
+        self.presampled = False
+        self.extras = engine.fused_extras(staged) if self.fused_tail else None
         if self.dp:
             e = engine
             e.adam.set_grad_scale(1.0 / self.world)
@@ -490,6 +521,21 @@ class DqnStepProgram(object):
 
     def _whole(self):
         e = self.e
+        if self.fused_tail and not e.overlap_wgrad:
+            # single rank: slab reduction and next-step index draw ride in the optimizer launch
+            if not self.staged and not (self.presampled and e.presamples(self.staged)):
+                with _Range("learner/sample"):
+                    e.sample()
+            with _Range("learner/forward+td_head"):
+                e.forward_head(self.staged)
+            with _Range("learner/backward_fc"):
+                e.backward_fc()
+            with _Range("learner/backward_conv"):
+                e.backward_conv(self.staged, reduce=False)
+            with _Range("learner/adam+target+tree"):
+                e.update(self.staged, extras=self.extras)
+            self.presampled = True
+            return
         if not e.overlap_wgrad:
             self._part_a()
             self._part_b()

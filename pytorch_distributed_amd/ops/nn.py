@@ -53,6 +53,8 @@ def _L():
         L.pda_conv_wgrad_u8.argtypes = [_vp] * 5 + [c_int] * 8 + [c_float, c_long, c_long, c_int, _vp]
         L.pda_wgrad_reduce.argtypes = [_vp] * 5 + [c_int, _vp]
         L.pda_col2im.argtypes = [_vp] * 3 + [c_int] * 8 + [_vp]
+        L.pda_linear_wgrad2.argtypes = [_vp] * 4 + [c_int] + [_vp] * 5 + [_vp]
+        L.pda_linear_wgrad2.restype = None
         L.pda_conv_dgrad.argtypes = [_vp] * 4 + [c_int] * 9 + [_vp]
         L.pda_conv_dgrad.restype = None
         L.pda_tr_probe.argtypes = [_vp, _vp]
@@ -130,6 +132,30 @@ def linear_wgrad(dy, x, gw, gb, B, Nout, Kin, lddy, ldx, ldg, scale=1.0, ksplit=
     assert ksplit == 0 or slice_stride >= Nout * ldg
     _L().pda_linear_wgrad(_ptr(dy), _ptr(x), _ptr(gw), _ptr(gb), B, Nout, Kin, lddy, ldx, ldg,
                           slice_stride, bslice_stride, float(scale), ksplit, _stream())
+
+
+class LinearWgradPair(object):
+    """Two single-slice linear weight gradients over the same batch as the two problem groups of one
+    launch.  jobs: [(dy, x, gw, gb, Nout, Kin, lddy, ldx, ldg)] x 2."""
+
+    def __init__(self, jobs, B):
+        assert len(jobs) == 2
+        self.keep, self.B = jobs, int(B)
+        self.dy = (_vp * 2)(*[j[0].data_ptr() for j in jobs])
+        self.x = (_vp * 2)(*[j[1].data_ptr() for j in jobs])
+        self.gw = (_vp * 2)(*[j[2].data_ptr() for j in jobs])
+        self.gb = (_vp * 2)(*[j[3].data_ptr() for j in jobs])
+        self.nout = (ctypes.c_int * 2)(*[int(j[4]) for j in jobs])
+        self.kin = (ctypes.c_int * 2)(*[int(j[5]) for j in jobs])
+        self.lddy = (ctypes.c_long * 2)(*[int(j[6]) for j in jobs])
+        self.ldx = (ctypes.c_long * 2)(*[int(j[7]) for j in jobs])
+        self.ldg = (ctypes.c_long * 2)(*[int(j[8]) for j in jobs])
+        for j in jobs:
+            assert j[6] % 8 == 0 and j[7] % 8 == 0
+
+    def run(self):
+        _L().pda_linear_wgrad2(self.dy, self.x, self.gw, self.gb, self.B, self.nout, self.kin, self.lddy,
+                               self.ldx, self.ldg, _stream())
 
 
 def conv_wgrad(dy, x, gw, gb, batch, H, W, C, KH, KW, S, O, ksplit=0, slice_stride=0, bslice_stride=0):

@@ -37,10 +37,11 @@ class SegmentTable(object):
         for si, e in enumerate(entries):
             rows.append([e["start"], e["count"], e.get("cols", e["count"]), e.get("C", 1),
                          e.get("P", e.get("cols", e["count"])), e.get("shadow_off", 0), e.get("shadow_ld", 0),
-                         1 if e.get("shadow", False) else 0])
+                         (1 if e.get("shadow", False) else 0) | (2 if e.get("fine", False) else 0)])
             cols, C, P = rows[-1][2], rows[-1][3], rows[-1][4]
             row_mode = bool(e.get("shadow", False)) and C > 1 and (P | 1) * C <= OPT_ROW_LDS
-            for first in range(0, e["count"], cols if row_mode else OPT_CHUNK):     # one row per block | flat chunks
+            step = cols if row_mode else (256 if e.get("fine", False) else OPT_CHUNK)
+            for first in range(0, e["count"], step):       # one row per block | flat chunks
                 chunks.append([si, first])
         self.segs = torch.tensor(rows, dtype=torch.int32).to(device)
         self.chunks = torch.tensor(chunks, dtype=torch.int32).to(device)
@@ -63,6 +64,11 @@ def plain_table(numel, device):
     return SegmentTable([{"start": 0, "count": int(numel)}], device)
 
 
+class AdamExtras(ctypes.Structure):     # mirrors AdamExtras in csrc/rl_kernels.hip
+    _fields_ = [("slab", _vp), ("slabinfo", _vp), ("next_idx", _vp), ("next_w", _vp), ("next_B", ctypes.c_int),
+                ("size", _vp), ("seed", ctypes.c_ulonglong), ("counter", _vp)]
+
+
 class FlatAdam(object):
     def __init__(self, flat_params, flat_grads, table, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  clip=np.inf, grad_scale=1.0, shadow=None):
@@ -77,13 +83,15 @@ class FlatAdam(object):
         L = lib()
         L.pda_adam.argtypes = [_vp] * 7 + [ctypes.c_int, _vp, _vp, _vp]
         L.pda_adam.restype = None
+        L.pda_adam_x.argtypes = [_vp] * 7 + [ctypes.c_int, _vp, _vp, ctypes.POINTER(AdamExtras), _vp]
+        L.pda_adam_x.restype = None
         L.pda_tick.argtypes = [_vp, _vp, _vp]
         L.pda_tick.restype = None
 
     def set_lr(self, lr):
         self.hyper[0] = float(lr)
 
-    def step(self, tick=False, table=None):
+    def step(self, tick=False, table=None, extras=None):
         """tick=True bumps the step counter with an extra tiny launch; engines whose
         loss kernel already bumps it (dqn_head / td_vector) pass False.  `table` restricts the
         launch to a subset of the segments (SegmentTable.subset) -- the DP step updates the fc
@@ -92,6 +100,11 @@ class FlatAdam(object):
             lib().pda_tick(_p(self.step_dev), _vp(0), _stream())
         t = table if table is not None else self.table
         if t.nchunks == 0:
+            return
+        if extras is not None:      # slab reduction and/or next-step sampler folded into this launch
+            lib().pda_adam_x(_p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.shadow), _p(t.segs),
+                             _p(t.chunks), t.nchunks, _p(self.hyper), _p(self.step_dev), ctypes.byref(extras),
+                             _stream())
             return
         lib().pda_adam(_p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.shadow), _p(t.segs),
                        _p(t.chunks), t.nchunks, _p(self.hyper), _p(self.step_dev), _stream())
