@@ -383,11 +383,12 @@ class DqnCnnEngine(object):
                  (a.dq, a.h1, self.gw[4], self.gb[4], g.A, g.HID, a.dq_ld, g.HID, g.HID)], B)
         self._fc_pair.run()
 
-    def fused_extras(self, staged):
-        """AdamExtras for a single-rank step: slab sums in the optimizer launch, plus (device replay,
+    def fused_extras(self, staged, slabs=True):
+        """AdamExtras: (single-rank steps) slab sums in the optimizer launch, plus (device replay,
         uniform sampling) the draw of the next step's replay indices."""
         x = AdamExtras()
-        x.slab, x.slabinfo = self.slab.data_ptr(), self.slabinfo.data_ptr()
+        if slabs:
+            x.slab, x.slabinfo = self.slab.data_ptr(), self.slabinfo.data_ptr()
         if self.presamples(staged):
             x.next_idx, x.next_w, x.next_B = self.idx.data_ptr(), self.isw.data_ptr(), self.B
             x.size, x.seed, x.counter = self.size_dev.data_ptr(), self.seed, self.counter.data_ptr()
@@ -490,6 +491,9 @@ class DqnStepProgram(object):
         self.fused_tail = (not self.dp) and os.environ.get("PDA_FUSED_TAIL", "1") != "0"
         self.presampled = False
         self.extras = engine.fused_extras(staged) if self.fused_tail else None
+        self.dp_extras = None
+        if self.dp and engine.presamples(staged) and os.environ.get("PDA_FUSED_TAIL", "1") != "0":
+            self.dp_extras = engine.fused_extras(staged, slabs=False)
         if self.dp:
             e = engine
             e.adam.set_grad_scale(1.0 / self.world)
@@ -503,7 +507,7 @@ class DqnStepProgram(object):
             self.head_table = e.online.table.subset(lambda s: s < first_tail_seg)
 
     def _part_a(self):
-        if not self.staged:
+        if not self.staged and not (self.presampled and self.e.presamples(self.staged)):
             with _Range("learner/sample"):
                 self.e.sample()
         with _Range("learner/forward+td_head"):
@@ -586,8 +590,9 @@ class DqnStepProgram(object):
         cur.wait_event(self.tail_done)
         e.adam.step(table=self.tail_table)          # fc tail update runs under the conv all-reduce
         cur.wait_event(self.head_done)
-        e.adam.step(table=self.head_table)
+        e.adam.step(table=self.head_table, extras=self.dp_extras)     # + next step's index draw
         e.post_update(self.staged)
+        self.presampled = self.dp_extras is not None
 
     def _dp_whole(self):
         self._run_dp(self._part_a, self._part_b)
