@@ -308,6 +308,10 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
                 global_logs.actor_step.value = restored[1]
                 print("[learner] resumed from %s at learner step %d" % (_resume_path(args), step))
     resume_freq = int(getattr(args, "resume_freq", 0))
+    # the reference has no actor/learner rate coupling: the replay ratio is whatever the
+    # two speeds give.  With a learner that is 15x faster that ratio explodes, so it can be capped:
+    # at most `max_replay_ratio` learner updates per env step taken by the actors (0 = unlimited)
+    max_ratio = float(getattr(ap, "max_replay_ratio", 0.0) or 0.0)
     started = False
     while step < ap.steps and not global_logs.stop.value:
         if hasattr(global_memory, "drain"):
@@ -317,6 +321,11 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
             started = comm.all_agree(ready)
             if not started:
                 time.sleep(0.05 if hasattr(global_memory, "drain") else 1.0)
+                continue
+        if max_ratio > 0:       # optional coupling of the learner to the data rate (absent in the reference)
+            behind = step - max_ratio * global_logs.actor_step.value
+            if comm.all_agree(behind <= 0) is False:
+                time.sleep(0.0005)
                 continue
         core.step()
         step += 1

@@ -38,7 +38,11 @@ CONFIGS = [
 PRESETS = {
     1: {"num_actors": 2, "agent_params.nstep": 1, "device": "cpu"},
     2: {"num_actors": 8, "agent_params.nstep": 5, "actor_inference": "batched"},
-    3: {"num_actors": 8, "agent_params.nstep": 5},
+    # DDPG: cap the replay ratio.  The reference's learner (~350 updates/s) never outruns its 8 actors; an
+    # uncoupled 8k-updates/s learner makes thousands of updates per turnover of a 50k replay, the tanh actor
+    # collapses to a constant saturated action and never recovers (measured: bench/learning_sanity.py,
+    # BASELINE.md).  0.005 updates per env step with the 50k replay, 0.02 with a 1M HBM replay both solve Pendulum.
+    3: {"num_actors": 8, "agent_params.nstep": 5, "agent_params.max_replay_ratio": 0.005},
     4: {"num_actors": 256, "actor_inference": "batched", "memory_params.memory_size": 2 * 1024 * 1024,
         "memory_params.enable_per": True, "agent_params.nstep": 5},
     5: {"num_actors": 256, "actor_inference": "batched", "memory_params.memory_size": 1024 * 1024,
@@ -46,7 +50,8 @@ PRESETS = {
     6: {"num_actors": 2, "agent_params.nstep": 3, "agent_params.learn_start": 200,
         "agent_params.batch_size": 32, "agent_params.target_model_update": 50,
         "agent_params.lr": 1e-3, "memory_params.memory_size": 5000},
-    7: {"num_actors": 8, "agent_params.nstep": 5},
+    7: {"num_actors": 8, "agent_params.nstep": 5, "agent_params.max_replay_ratio": 0.02,
+        "memory_params.memory_size": 1024 * 1024, "agent_params.learn_start": 20000},
 }
 
 
@@ -209,6 +214,7 @@ class AgentParams(Params):
         self.tester_nepisodes = 50
         self.evaluator_nepisodes = 2
         self.nstep = 5
+        self.max_replay_ratio = 0.0     # cap on learner updates per actor env step (0: none, as in the reference)
         self.poll_interval = 5.0        # logger/evaluator wake-up period (secs; the reference hard-codes 5)
         if self.agent_type == "dqn":
             self.clip_grad = np.inf
