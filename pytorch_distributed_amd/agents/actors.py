@@ -46,12 +46,60 @@ def _maybe_fault(args, role, process_ind, step):
         pass
 
 
+class _EnvWorker(object):
+    """One env of an actor process with its n-step feeder, episode bookkeeping and (batched
+    inference) mailbox slot.  begin() returns the observation to act on, finish() takes the action."""
+
+    def __init__(self, args, kind, env, feeder, slot, eps, random_process, enable_per):
+        self.args, self.kind, self.env, self.feeder, self.slot = args, kind, env, feeder, slot
+        self.eps, self.random_process, self.enable_per = eps, random_process, enable_per
+        self.early_stop = args.env_params.early_stop
+        self.experience = reset_experience()
+        self.flag_reset = True      # terminal1 or episode_steps reached early_stop
+        self.episode_steps, self.episode_reward = 0, 0.0
+        self.total_steps, self.total_reward, self.nepisodes, self.nepisodes_solved = 0, 0.0, 0, 0
+
+    def begin(self):
+        if self.flag_reset:
+            self.episode_steps, self.episode_reward = 0, 0.0
+            self.experience = self.env.reset()
+            assert self.experience.state1 is not None
+            self.feeder.reset(self.experience.state1)
+            self.flag_reset = False
+        return self.experience.state1
+
+    def finish(self, action, qvalue, max_qvalue, last_q_fn):
+        """Step the env with `action`; last_q_fn(state) -> max_a Q(state) is only called when an
+        episode ends with PER on (priority of the closing transition)."""
+        if self.kind == "ddpg":
+            action = action + self.random_process.sample()
+        self.experience = exp = self.env.step(action)
+        self.feeder.push(exp.action, exp.reward, exp.state1, exp.terminal1, qvalue, max_qvalue)
+        if exp.terminal1:
+            self.nepisodes_solved += 1
+            self.flag_reset = True
+        if self.early_stop and (self.episode_steps + 1) >= self.early_stop:
+            self.flag_reset = True
+        if self.flag_reset:
+            self.feeder.flush(last_q_fn(exp.state1) if self.enable_per else None)
+        self.episode_steps += 1
+        self.episode_reward += exp.reward
+        if self.flag_reset:
+            self.nepisodes += 1
+            self.total_steps += self.episode_steps
+            self.total_reward += self.episode_reward
+
+    def drain_stats(self):
+        out = (self.total_steps, self.total_reward, self.nepisodes, self.nepisodes_solved)
+        self.total_steps, self.total_reward, self.nepisodes, self.nepisodes_solved = 0, 0.0, 0, 0
+        return out
+
+
 def _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model_prototype,
                 global_memory, global_model, kind):
     print("---------------------------->", process_ind, "actor")
     ap, mp_ = args.agent_params, args.memory_params
-    env = env_prototype(args.env_params, process_ind, args.num_envs_per_actor)
-    env.train()
+    E = max(1, int(args.num_envs_per_actor))    # the reference asserts 1 (atari_env.py:15); here E envs per process
     rng = np.random.RandomState(args.seed + 7919 * process_ind)
 
     mailbox = getattr(global_model, "mailbox", None) if args.actor_inference == "batched" else None
@@ -72,84 +120,64 @@ def _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model
             pass
 
     enable_per = bool(mp_.enable_per) and kind == "dqn"
-    if kind == "dqn":
-        eps = actor_epsilon(process_ind, args.num_actors, ap.eps, ap.eps_alpha)
-        if mailbox is not None:
-            mailbox.set_epsilon(process_ind - 1, eps)
-    else:
-        random_process = ap.random_process(size=args.action_space, theta=0.15, sigma=0.3,
-                                           n_steps_annealing=mp_.memory_size * 100)
-
-    def act(state):
+    workers = []
+    for e in range(E):
+        index = (process_ind - 1) * E + e           # global env index: mailbox slot and rung of the eps ladder
+        env = env_prototype(args.env_params, process_ind if E == 1 else 1 + index, E)
+        env.train()
+        eps, random_process = None, None
         if kind == "dqn":
+            eps = actor_epsilon(1 + index, args.num_actors * E, ap.eps, ap.eps_alpha)
             if mailbox is not None:
-                return mailbox.request(process_ind - 1, state)
-            return local_model.get_action(state, enable_per, eps, device=local_device, rng=rng)
-        noise = random_process.sample()
+                mailbox.set_epsilon(index, eps)
+        else:
+            random_process = ap.random_process(size=args.action_space, theta=0.15, sigma=0.3,
+                                               n_steps_annealing=mp_.memory_size * 100)
+        feeder = make_feeder(global_memory, ap.nstep, ap.gamma, enable_per,
+                             native=getattr(args, "native_nstep", True))
+        workers.append(_EnvWorker(args, kind, env, feeder, index, eps, random_process, enable_per))
+
+    def local_act(w, state):
+        if kind == "dqn":
+            return local_model.get_action(state, enable_per, w.eps, device=local_device, rng=rng)
+        return local_model.get_action(state, 0.0, device=local_device)
+
+    def last_q(w):
         if mailbox is not None:
-            a, q, mq = mailbox.request(process_ind - 1, state)
-            return a + noise, q, mq
-        return local_model.get_action(state, noise, device=local_device)
+            return lambda state: mailbox.request(w.slot, state)[2]
+        return lambda state: local_model.get_action(state, True, w.eps, device=local_device, rng=rng)[2]
 
-    feeder = make_feeder(global_memory, ap.nstep, ap.gamma, enable_per,
-                         native=getattr(args, "native_nstep", True))
-    experience = reset_experience()
     step = 0
-    episode_steps, episode_reward = 0, 0.0
-    total_steps, total_reward, nepisodes, nepisodes_solved = 0, 0.0, 0, 0
-    flag_reset = True   # terminal1 or episode_steps reached early_stop
+    pending = None
+    if mailbox is not None:     # every env has one request in flight; the server batches across actors
+        pending = [mailbox.send(w.slot, w.begin()) for w in workers]
     while global_logs.running(ap.steps):
-        if flag_reset:
-            episode_steps, episode_reward = 0, 0.0
-            experience = env.reset()
-            assert experience.state1 is not None
-            feeder.reset(experience.state1)
-            flag_reset = False
+        for j, w in enumerate(workers):
+            if mailbox is not None:
+                action, qvalue, max_qvalue = mailbox.wait(w.slot, pending[j])
+            else:
+                action, qvalue, max_qvalue = local_act(w, w.begin())
+            w.finish(action, qvalue, max_qvalue, last_q(w))
+            if mailbox is not None:
+                pending[j] = mailbox.send(w.slot, w.begin())    # in flight while the other envs are stepped
 
-        action, qvalue, max_qvalue = act(experience.state1)
-        experience = env.step(action)
-
-        feeder.push(experience.action, experience.reward, experience.state1, experience.terminal1,
-                    qvalue, max_qvalue)
-
-        if experience.terminal1:
-            nepisodes_solved += 1
-            flag_reset = True
-        if args.env_params.early_stop and (episode_steps + 1) >= args.env_params.early_stop:
-            flag_reset = True
-
-        if flag_reset:
-            max_q_last = None
-            if enable_per:      # one extra forward of the final state for its priority
-                if mailbox is not None:
-                    _, _, max_q_last = mailbox.request(process_ind - 1, experience.state1)
-                else:
-                    _, _, max_q_last = local_model.get_action(experience.state1, True, eps,
-                                                              device=local_device, rng=rng)
-            feeder.flush(max_q_last)
-
-        with global_logs.actor_step.get_lock():
-            global_logs.actor_step.value += 1
-        step += 1
-        episode_steps += 1
-        episode_reward += experience.reward
-        if flag_reset:
-            nepisodes += 1
-            total_steps += episode_steps
-            total_reward += episode_reward
-
-        if local_model is not None and step % ap.actor_sync_freq == 0:
-            sync_params(local_model, global_model)
-
-        if step % ap.actor_freq == 0:   # push local stats to the logger, then reset them
-            with actor_logs.nepisodes.get_lock():
-                actor_logs.total_steps.value += total_steps
-                actor_logs.total_reward.value += total_reward
-                actor_logs.nepisodes.value += nepisodes
-                actor_logs.nepisodes_solved.value += nepisodes_solved
-            total_steps, total_reward, nepisodes, nepisodes_solved = 0, 0.0, 0, 0
-            global_logs.beat("actor")
-        _maybe_fault(args, "actor", process_ind, step)
+            with global_logs.actor_step.get_lock():
+                global_logs.actor_step.value += 1
+            step += 1
+            if local_model is not None and step % ap.actor_sync_freq == 0:
+                sync_params(local_model, global_model)
+            if step % ap.actor_freq == 0:   # push local stats to the logger, then reset them
+                tot = [0, 0.0, 0, 0]
+                for ww in workers:
+                    for i, v in enumerate(ww.drain_stats()):
+                        tot[i] += v
+                with actor_logs.nepisodes.get_lock():
+                    actor_logs.total_steps.value += tot[0]
+                    actor_logs.total_reward.value += tot[1]
+                    actor_logs.nepisodes.value += tot[2]
+                    actor_logs.nepisodes_solved.value += tot[3]
+                global_logs.beat("actor")
+            _maybe_fault(args, "actor", process_ind, step)
 
 
 def dqn_actor(process_ind, args, global_logs, actor_logs, env_prototype, model_prototype,

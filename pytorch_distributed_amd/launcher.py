@@ -137,7 +137,7 @@ def run(opt):
 
     if opt.actor_inference == "batched":
         from .parallel.inference_server import InferenceMailbox
-        global_model.mailbox = InferenceMailbox(opt.num_actors, opt.state_shape,
+        global_model.mailbox = InferenceMailbox(opt.num_actors * max(1, int(opt.num_envs_per_actor)), opt.state_shape,
                                                 global_memory.state_dtype if hasattr(global_memory, "state_dtype")
                                                 else torch.float32,
                                                 opt.action_shape, discrete=(opt.agent_type == "dqn"))

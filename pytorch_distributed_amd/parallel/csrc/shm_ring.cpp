@@ -456,6 +456,12 @@ uint64_t pda_mailbox_request(void* seq_base, int slot, uint64_t k, void* obs_dst
     pda_mailbox::req_word(seq_base, slot)->store(k, std::memory_order_release);
     return pda_mailbox::wait_response(seq_base, slot, k, spins, timeout_us);
 }
+// Split form for actors that drive several envs: send() posts without waiting, so the server works on
+// env A's request while the actor steps env B; pda_mailbox_wait collects the answer later.
+void pda_mailbox_send(void* seq_base, int slot, uint64_t k, void* obs_dst, const void* obs_src, uint64_t obs_bytes) {
+    if (obs_bytes) std::memcpy(obs_dst, obs_src, obs_bytes);
+    pda_mailbox::req_word(seq_base, slot)->store(k, std::memory_order_release);
+}
 uint64_t pda_mailbox_wait(void* seq_base, int slot, uint64_t k, uint32_t spins, uint32_t timeout_us) {
     return pda_mailbox::wait_response(seq_base, slot, k, spins, timeout_us);
 }

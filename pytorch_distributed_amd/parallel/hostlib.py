@@ -77,6 +77,8 @@ def lib():
         L.pda_nstep_flush.argtypes = [vp, vp, dbl, i32, u32]
         L.pda_mailbox_request.restype = u64
         L.pda_mailbox_request.argtypes = [vp, i32, u64, vp, vp, u64, u32, u32]
+        L.pda_mailbox_send.restype = None
+        L.pda_mailbox_send.argtypes = [vp, i32, u64, vp, vp, u64]
         L.pda_mailbox_wait.restype = u64
         L.pda_mailbox_wait.argtypes = [vp, i32, u64, u32, u32]
         L.pda_mailbox_collect.restype = i32

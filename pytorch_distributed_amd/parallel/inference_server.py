@@ -59,20 +59,26 @@ class InferenceMailbox(object):
         return self._views()[2] + slot * 128 + 64
 
     # ---- actor side --------------------------------------------------------
-    def request(self, slot, state, timeout_s=120.0):
-        """Post one observation and block until the server answers: one C call that copies the
-        observation into the slot, release-stores the request number, spins briefly and then
-        sleeps on a futex (parallel/csrc/mailbox.h) -- the GIL is released throughout."""
+    def send(self, slot, state):
+        """Post one observation without waiting (pair with wait()): an actor that drives several
+        envs steps env B while the server answers env A.  Returns the request number."""
         L = hostlib.lib()
-        obs, out, seq = self._views()
+        obs, _, seq = self._views()
         src = np.ascontiguousarray(state, dtype=obs.dtype).reshape(-1)
         k = self._count.get(slot)
         if k is None:
             k = int(L.pda_atomic_load(self._req_ptr(slot)))
         k += 1
         self._count[slot] = k
-        row = obs[slot]
-        got = L.pda_mailbox_request(seq, slot, k, row.ctypes.data, src.ctypes.data, src.nbytes, 4000, 2000)
+        L.pda_mailbox_send(seq, slot, k, obs[slot].ctypes.data, src.ctypes.data, src.nbytes)
+        return k
+
+    def wait(self, slot, k, timeout_s=120.0):
+        """Block until request k of `slot` is answered: a short spin, then a futex sleep
+        (parallel/csrc/mailbox.h); the GIL is released throughout."""
+        L = hostlib.lib()
+        _, out, seq = self._views()
+        got = L.pda_mailbox_wait(seq, slot, k, 4000, 2000)
         deadline = None
         while got < k:
             if int(self.closed[0]) != 0:      # job is shutting down: hand back a no-op action
@@ -91,6 +97,10 @@ class InferenceMailbox(object):
         else:
             action = row[:a].astype(np.float64).reshape(1, a)
         return action, float(row[a]), float(row[a + 1])
+
+    def request(self, slot, state, timeout_s=120.0):
+        """Post one observation and block until the server answers."""
+        return self.wait(slot, self.send(slot, state), timeout_s)
 
     # ---- server side (host fallback; the GPU path is ops/infer.py) -----------------------
     def pending(self):
@@ -128,10 +138,10 @@ class BatchedPolicy(object):
             from .. import ops
             if ops.native_available() and args.model_type == "dqn-cnn":
                 from ..ops.dqn_engine import DqnCnnInference
-                self.engine = DqnCnnInference(model, max_batch=max(args.num_actors, 1))
+                self.engine = DqnCnnInference(model, max_batch=max(args.num_actors * max(1, int(args.num_envs_per_actor)), 1))
             elif ops.native_available() and args.model_type == "ddpg-mlp":
                 from ..ops.mlp_engine import DdpgActorInference
-                self.engine = DdpgActorInference(model, max_batch=max(args.num_actors, 1))
+                self.engine = DdpgActorInference(model, max_batch=max(args.num_actors * max(1, int(args.num_envs_per_actor)), 1))
 
     def refresh(self):
         if self.engine is not None:

@@ -101,3 +101,15 @@ def test_resume_sidecar_continues_training(tmp_root):
     b = load_resume(side)
     assert b["learner_step"] == 50 and b["opt_step"] == 50          # 20 more optimizer steps, not 50
     assert not torch.equal(a["params"], b["params"])
+
+
+def test_multi_env_actors_with_batched_inference(tmp_root):
+    """num_envs_per_actor > 1 (the reference asserts 1): each actor process drives 3 envs with one
+    inference request in flight per env; 2 x 3 mailbox slots, a 6-rung epsilon ladder."""
+    opt = opts(4, tmp_root, num_actors=2, num_envs_per_actor=3, timestamp="venv",
+               **{"agent_params.steps": 25, "agent_params.learn_start": 40, "agent_params.batch_size": 8,
+                  "memory_params.memory_size": 256, "memory_params.ingest_ring_slots": 64,
+                  "memory_params.ingest_chunk": 16})
+    assert opt.env_params.num_envs_per_actor == 3
+    sup = run(opt)
+    check_common(opt, sup, 25)
