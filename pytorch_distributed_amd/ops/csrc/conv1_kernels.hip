@@ -1,0 +1,243 @@
+// Nature-CNN conv1 (8x8 kernel, stride 4, 32 output channels, uint8 planar frames) -- forward and
+// weight gradient specialised for gfx950.
+//
+// The generic implicit-GEMM loader (gemm.h, SrcFrameU8K/T) fetches every 8-byte kernel row of every
+// output pixel straight from global memory: 8-byte accesses at 84-byte strides, each input byte
+// fetched 4 times, u8->bf16 conversion repeated per use.  At batch 4096 that made conv1 the two most
+// expensive launches of the learner step (365 + 470 us of 2.2 ms, profiles/r1_dqn_step_batch4096_rocprof.txt).
+// Here one workgroup owns whole images:
+//   * the 4x84x84 frame stack (28 KB, gathered through the replay index) is read ONCE with coalesced
+//     16-byte loads, converted to bf16 once and kept in LDS (56 KB);
+//   * forward: an MFMA A-fragment (pixel, 8 consecutive kx) is two ds_read_b64 of that patch; the
+//     32x256 weights live in registers as B-fragments for the whole kernel (64 VGPRs);
+//   * weight gradient: per 32 output pixels the im2col rows are expanded LDS->LDS into a [pixel][k]
+//     tile and both operands come back through CDNA4's transposing ds_read_b64_tr_b16, accumulators
+//     stay in registers across all images of the workgroup (split-K over images, one slab slice each).
+#include "gemm.h"
+#include "api.h"
+
+namespace {
+
+struct Conv1Geom { int C, H, W, OH, OW; };
+
+// 16 uint8 -> 16 bf16 (exact), as two uint4
+__device__ __forceinline__ void u8x16_to_bf16(uint4 v, uint4& lo, uint4& hi) {
+    uint2 a = u8x4_to_bf16x4(v.x), b = u8x4_to_bf16x4(v.y), c = u8x4_to_bf16x4(v.z), d = u8x4_to_bf16x4(v.w);
+    lo = make_uint4(a.x, a.y, b.x, b.y);
+    hi = make_uint4(c.x, c.y, d.x, d.y);
+}
+
+// frame stack of image `img` -> bf16 patch in LDS, same linear [c][y][x] order
+__device__ __forceinline__ void load_patch(const uint8_t* frames, const int* idx, long frame_bytes, int img,
+                                           bf16_t* patch, int tid) {
+    long f = idx ? (long)idx[img] : (long)img;
+    const uint4* src = reinterpret_cast<const uint4*>(frames + f * frame_bytes);
+    int n16 = (int)(frame_bytes >> 4);
+    for (int t = tid; t < n16; t += 256) {
+        uint4 lo, hi;
+        u8x16_to_bf16(src[t], lo, hi);
+        uint4* dst = reinterpret_cast<uint4*>(patch + (long)t * 16);
+        dst[0] = lo;
+        dst[1] = hi;
+    }
+}
+
+__device__ __forceinline__ bf16x8 patch_frag(const bf16_t* p) {     // 8 consecutive bf16, 8-byte aligned
+    uint2 a = *reinterpret_cast<const uint2*>(p);
+    uint2 b = *reinterpret_cast<const uint2*>(p + 4);
+    uint4 v = make_uint4(a.x, a.y, b.x, b.y);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+struct Conv1FwdArgs {
+    const uint8_t* frames[GEMM_MAX_GROUPS]; const int* idx[GEMM_MAX_GROUPS]; const bf16_t* w[GEMM_MAX_GROUPS];
+    const float* bias[GEMM_MAX_GROUPS]; bf16_t* out[GEMM_MAX_GROUPS];
+    int batch; Conv1Geom g; float scale; int act;
+};
+
+// grid (blocks, groups); each block loops over images blockIdx.x, += gridDim.x
+template <int C>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t patch[];
+    constexpr int KS = 2 * C;           // k-steps of 32: (c, ky half)
+    constexpr int K = 64 * C;
+    const int grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const Conv1Geom g = a.g;
+    const int P = g.OH * g.OW, nrb = (P + 15) >> 4;
+    const long frame_bytes = (long)C * g.H * g.W;
+    // weights as B fragments: lane (n = l15 + 16 nb, k = 32 ks + 8 g4 .. +7)
+    bf16x8 wf[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+            wf[ks][nb] = *reinterpret_cast<const bf16x8*>(a.w[grp] + (long)(nb * 16 + l15) * K + ks * 32 + g4 * 8);
+    const float b0 = a.bias[grp] ? a.bias[grp][l15] : 0.f, b1 = a.bias[grp] ? a.bias[grp][16 + l15] : 0.f;
+
+    for (int img = blockIdx.x; img < a.batch; img += gridDim.x) {
+        __syncthreads();                // everyone is done reading the previous patch
+        load_patch(a.frames[grp], a.idx[grp], frame_bytes, img, patch, tid);
+        __syncthreads();
+        bf16_t* out = a.out[grp] + (long)img * P * 32;
+        for (int rb = wave; rb < nrb; rb += 4) {
+            int m = rb * 16 + l15;
+            int mm = m < P ? m : 0;
+            int oy = mm / g.OW, ox = mm - oy * g.OW;
+            const bf16_t* base = patch + (4 * oy) * g.W + 4 * ox;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                int c = ks >> 1, ky = (ks & 1) * 4 + g4;
+                bf16x8 af = patch_frag(base + (long)c * g.H * g.W + ky * g.W);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf[ks][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf[ks][1], acc1, 0, 0, 0);
+            }
+            // D layout: col = lane & 15, row = (lane >> 4) * 4 + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int pix = rb * 16 + g4 * 4 + r;
+                if (pix < P) {
+                    out[(long)pix * 32 + l15] = f2bf(apply_act(acc0[r] * a.scale + b0, a.act));
+                    out[(long)pix * 32 + 16 + l15] = f2bf(apply_act(acc1[r] * a.scale + b1, a.act));
+                }
+            }
+        }
+    }
+}
+
+struct Conv1WgradArgs {
+    const uint8_t* frames; const int* idx; const bf16_t* dy;    // dy [(b, oy, ox)][32] bf16
+    float* gw; float* gb; long slice_stride, bslice_stride;     // slab slice blockIdx.x
+    int batch; Conv1Geom g; float scale;
+};
+
+// LDS: patch [C*H*W] | dyT [PP][32] (T layout, ROWS = 32) | col 4 x [32 px][64 k] (T layout, ROWS = 64)
+template <int C>
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    constexpr int K = 64 * C;           // 256
+    static_assert(C == 4, "column tile split assumes K == 256 (four 64-wide sub-tiles, one per wave)");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Conv1Geom g = a.g;
+    const int P = g.OH * g.OW, PP = (P + 31) / 32 * 32, nchunk = PP / 32;
+    const long frame_bytes = (long)C * g.H * g.W;
+    bf16_t* patch = lds;
+    bf16_t* dyt = patch + frame_bytes;
+    bf16_t* col = dyt + (long)PP * 32;
+
+    f32x4 acc[2][4];
+    f32x4 accb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+
+    for (int img = blockIdx.x; img < a.batch; img += gridDim.x) {
+        __syncthreads();
+        load_patch(a.frames, a.idx, frame_bytes, img, patch, tid);
+        // dy rows of this image -> T layout [px][32]: 4 x 16-byte chunks per pixel row, chunk pair j = 2 rg
+        const uint4* dsrc = reinterpret_cast<const uint4*>(a.dy + (long)img * P * 32);
+        for (int t = tid; t < PP * 4; t += 256) {
+            int px = t >> 2, rg = t & 3;
+            uint4 v = px < P ? dsrc[t] : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(dyt + px * 32 + (((2 * rg) ^ swz_t<32>(px)) << 2)) = v;
+        }
+        for (int ch = 0; ch < nchunk; ++ch) {
+            __syncthreads();            // patch / dyt ready (first chunk); previous chunk's col consumed
+            // expand im2col rows of pixels [32 ch, 32 ch + 32): item = (px, j = (c, ky)) -> 8 bf16 (kx 0..7)
+            for (int t = tid; t < 32 * (K / 8); t += 256) {
+                int pl = t / (K / 8), j = t - pl * (K / 8);
+                int px = ch * 32 + pl;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (px < P) {
+                    int oy = px / g.OW, ox = px - oy * g.OW;
+                    int c = j >> 3, ky = j & 7;
+                    const bf16_t* p = patch + (long)c * g.H * g.W + (4 * oy + ky) * g.W + 4 * ox;
+                    uint2 lo = *reinterpret_cast<const uint2*>(p), hi = *reinterpret_cast<const uint2*>(p + 4);
+                    v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+                // k index = 8 j .. 8 j + 7 -> sub-tile (8 j) / 64, row group ((8 j) % 64) / 8
+                int sub = j >> 3, rg = j & 7;
+                *reinterpret_cast<uint4*>(col + sub * (32 * 64) + pl * 64 + (((2 * rg) ^ swz_t<64>(pl)) << 2)) = v;
+            }
+            __syncthreads();
+            bf16x8 fa[2], fb[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = read_frag<true, 32, 32>(dyt + ch * 32 * 32, i * 16, 0, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = read_frag<true, 64, 32>(col + wave * (32 * 64), j * 16, 0, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (wave == 0) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+    }
+    // this block's partial [32][K] tile -> slab slice blockIdx.x (kernel layout == PyTorch's (c, ky, kx))
+    float* dw = a.gw + (long)blockIdx.x * a.slice_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int o = i * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int k = wave * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dw[(long)(o + r) * K + k] = acc[i][j][r] * a.scale;
+        }
+        if (wave == 0 && (lane & 15) == 0 && a.gb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.gb[(long)blockIdx.x * a.bslice_stride + o + r] = accb[i][r];
+        }
+    }
+}
+
+}  // namespace
+
+// Does the specialised path cover this conv?  (Nature conv1 on 4-frame stacks)
+PDA_EXPORT int pda_conv1_supported(int H, int W, int C, int KH, int KW, int S, int O) {
+    return (C == 4 && KH == 8 && KW == 8 && S == 4 && O == 32 && W % 4 == 0 && ((long)C * H * W) % 16 == 0 &&
+            (long)C * H * W * 2 <= 64 * 1024) ? 1 : 0;
+}
+
+PDA_EXPORT void pda_conv1_fwd_u8(const void* const* frames, const void* const* idx, const void* const* w,
+                                 const void* const* bias, void* const* out, int ngroups, int batch, int H, int W,
+                                 int C, float scale, int act, hipStream_t stream) {
+    Conv1FwdArgs a;
+    for (int i = 0; i < ngroups; ++i) {
+        a.frames[i] = (const uint8_t*)frames[i]; a.idx[i] = (const int*)idx[i]; a.w[i] = (const bf16_t*)w[i];
+        a.bias[i] = (const float*)bias[i]; a.out[i] = (bf16_t*)out[i];
+    }
+    a.batch = batch; a.g = {C, H, W, (H - 8) / 4 + 1, (W - 8) / 4 + 1}; a.scale = scale; a.act = act;
+    int blocks = batch < 512 ? batch : 512;     // 2 resident per CU (56 KB LDS each)
+    size_t lds = (size_t)C * H * W * 2;
+    hipLaunchKernelGGL(conv1_fwd_kernel<4>, dim3(blocks, ngroups), dim3(256), lds, stream, a);
+}
+
+// Slices the weight-gradient launch writes for this batch (one per workgroup).
+PDA_EXPORT int pda_conv1_wgrad_slices(int batch) { return batch < 256 ? batch : 256; }
+
+PDA_EXPORT void pda_conv1_wgrad_u8(const void* dy, const void* frames, const void* idx, void* gw, void* gb,
+                                   int batch, int H, int W, int C, float scale, long slice_stride,
+                                   long bslice_stride, hipStream_t stream) {
+    Conv1WgradArgs a;
+    a.frames = (const uint8_t*)frames; a.idx = (const int*)idx; a.dy = (const bf16_t*)dy;
+    a.gw = (float*)gw; a.gb = (float*)gb; a.slice_stride = slice_stride; a.bslice_stride = bslice_stride;
+    a.batch = batch; a.g = {C, H, W, (H - 8) / 4 + 1, (W - 8) / 4 + 1}; a.scale = scale;
+    int P = a.g.OH * a.g.OW, PP = (P + 31) / 32 * 32;
+    size_t lds = ((size_t)C * H * W + (size_t)PP * 32 + 4 * 32 * 64) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_wgrad_kernel<4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv1_wgrad_kernel<4>, dim3(pda_conv1_wgrad_slices(batch)), dim3(256), lds, stream, a);
+}

@@ -295,6 +295,8 @@ class DqnCnnEngine(object):
             tiles = ((O + 63) // 64 if O > 32 else 1) * ((K + 63) // 64)
             ks = _ksplit(red, tiles, 512, 128)
             ns = nn.num_slices(red, ks)
+            if li == 0 and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32):
+                ns = nn.conv1_wgrad_slices(B)       # whole-image kernel: one slice per workgroup
             plans.append((li, O, K, ks, ns))
         self.wg_plan = plans
         total = sum(ns * (O * K + O) for _, O, K, _, ns in plans)

@@ -53,6 +53,14 @@ def _L():
         L.pda_conv_wgrad_u8.argtypes = [_vp] * 5 + [c_int] * 8 + [c_float, c_long, c_long, c_int, _vp]
         L.pda_wgrad_reduce.argtypes = [_vp] * 5 + [c_int, _vp]
         L.pda_col2im.argtypes = [_vp] * 3 + [c_int] * 8 + [_vp]
+        L.pda_conv1_supported.argtypes = [c_int] * 7
+        L.pda_conv1_supported.restype = c_int
+        L.pda_conv1_fwd_u8.argtypes = [_vp] * 5 + [c_int] * 5 + [c_float, c_int, _vp]
+        L.pda_conv1_fwd_u8.restype = None
+        L.pda_conv1_wgrad_slices.argtypes = [c_int]
+        L.pda_conv1_wgrad_slices.restype = c_int
+        L.pda_conv1_wgrad_u8.argtypes = [_vp] * 5 + [c_int] * 4 + [c_float, c_long, c_long, _vp]
+        L.pda_conv1_wgrad_u8.restype = None
         L.pda_linear_wgrad2.argtypes = [_vp] * 4 + [c_int] + [_vp] * 5 + [_vp]
         L.pda_linear_wgrad2.restype = None
         L.pda_conv_dgrad.argtypes = [_vp] * 4 + [c_int] * 9 + [_vp]
@@ -69,9 +77,23 @@ def conv_out(h, k, s):
     return (h - k) // s + 1
 
 
+def conv1_specialised(H, W, C, KH, KW, S, O):
+    """True when the whole-image conv1 kernels (csrc/conv1_kernels.hip) cover this layer."""
+    import os
+    return os.environ.get("PDA_CONV1_GENERIC", "0") != "1" and bool(_L().pda_conv1_supported(H, W, C, KH, KW, S, O))
+
+
+def conv1_wgrad_slices(batch):
+    return int(_L().pda_conv1_wgrad_slices(int(batch)))
+
+
 def conv_fwd_u8(frames, idx, w, bias, out, batch, H, W, C, KH, KW, S, O, scale, act=ACT_RELU):
     """Lists (one entry per problem group, <= 3).  frames: uint8 [*, C, H, W]; idx: int32 [batch] or None."""
     assert KW == 8 and len(frames) <= 3
+    if conv1_specialised(H, W, C, KH, KW, S, O):
+        _L().pda_conv1_fwd_u8(_arr(frames), _arr(idx), _arr(w), _arr(bias), _arr(out), len(frames), batch,
+                              H, W, C, float(scale), act, _stream())
+        return
     _L().pda_conv_fwd_u8(_arr(frames), _arr(idx), _arr(w), _arr(bias), _arr(out), len(frames), batch,
                          H, W, C, KH, KW, S, O, float(scale), act, _stream())
 
@@ -168,6 +190,12 @@ def conv_wgrad(dy, x, gw, gb, batch, H, W, C, KH, KW, S, O, ksplit=0, slice_stri
 def conv_wgrad_u8(dy, frames, idx, gw, gb, batch, H, W, C, KH, KW, S, O, scale, ksplit=0, slice_stride=0,
                   bslice_stride=0):
     assert ksplit == 0 or slice_stride >= O * C * KH * KW
+    if conv1_specialised(H, W, C, KH, KW, S, O):
+        # one slice per workgroup (conv1_wgrad_slices(batch) of them); ksplit is not used
+        assert conv1_wgrad_slices(batch) == 1 or slice_stride >= O * C * KH * KW
+        _L().pda_conv1_wgrad_u8(_ptr(dy), _ptr(frames), _ptr(idx), _ptr(gw), _ptr(gb), batch, H, W, C,
+                                float(scale), slice_stride, bslice_stride, _stream())
+        return
     _L().pda_conv_wgrad_u8(_ptr(dy), _ptr(frames), _ptr(idx), _ptr(gw), _ptr(gb), batch, H, W, C, KH, KW, S, O,
                            float(scale), slice_stride, bslice_stride, ksplit, _stream())
 

@@ -65,8 +65,13 @@ def test_linear_fwd_grouped_tanh(nn):
         close(o, torch.tanh(x @ w.t() + b), 1e-3, 1e-3)
 
 
-@pytest.mark.parametrize("batch,use_idx", [(32, True), (5, False)])
-def test_conv1_fwd_u8(nn, batch, use_idx):
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("batch,use_idx", [(32, True), (5, False), (600, True)])
+def test_conv1_fwd_u8(nn, batch, use_idx, generic, monkeypatch):
+    """generic: the implicit-GEMM loader of gemm.h; otherwise the whole-image kernel of conv1_kernels.hip
+    (600 images > 512 workgroups: the per-block image loop)."""
+    monkeypatch.setenv("PDA_CONV1_GENERIC", "1" if generic else "0")
+    assert nn.conv1_specialised(84, 84, 4, 8, 8, 4, 32) == (not generic)
     torch.manual_seed(2)
     mem = torch.randint(0, 256, (64, 4, 84, 84), dtype=torch.uint8, device="cuda")
     idx = torch.randint(0, 64, (batch,), dtype=torch.int32, device="cuda") if use_idx else None
@@ -166,9 +171,11 @@ def test_conv_backward_nhwc(nn, geom):
     close(nn.from_nhwc(dx2, batch, H, W, C), x.grad * (x.detach() > 0), 3e-2, 3e-2)
 
 
-def test_conv1_wgrad_u8(nn):
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("batch", [8, 300])
+def test_conv1_wgrad_u8(nn, batch, generic, monkeypatch):
+    monkeypatch.setenv("PDA_CONV1_GENERIC", "1" if generic else "0")
     torch.manual_seed(6)
-    batch = 8
     mem = torch.randint(0, 256, (32, 4, 84, 84), dtype=torch.uint8, device="cuda")
     idx = torch.randint(0, 32, (batch,), dtype=torch.int32, device="cuda")
     x = mem[idx.long()].float() / 255.0
@@ -176,7 +183,7 @@ def test_conv1_wgrad_u8(nn):
     b = torch.zeros(32, device="cuda", requires_grad=True)
     dy = bf(torch.randn(batch, 32, 20, 20, device="cuda"))
     F.conv2d(x, w, b, stride=4).backward(dy)
-    ns = nn.num_slices(batch * 400, 512)
+    ns = nn.num_slices(batch * 400, 512) if generic else nn.conv1_wgrad_slices(batch)
     slab = torch.full((ns, 32 * 256), 7.0, device="cuda")
     bslab = torch.full((ns, 32), 7.0, device="cuda")
     nn.conv_wgrad_u8(nn.nhwc(dy), mem, idx, slab, bslab, batch, 84, 84, 4, 8, 8, 4, 32, 1.0 / 255.0, ksplit=512,
@@ -184,5 +191,6 @@ def test_conv1_wgrad_u8(nn):
     gw = torch.zeros(32, 256, device="cuda")
     gb = torch.zeros(32, device="cuda")
     nn.ReducePlan([(slab, gw, 32 * 256, ns, 32 * 256), (bslab, gb, 32, ns, 32)]).run()
-    close(gw.reshape(32, 4, 8, 8), w.grad, 2e-3, 2e-3)
-    close(gb, b.grad, 2e-3, 2e-3)
+    tol = 2e-3 * max(1.0, batch / 8) ** 0.5
+    close(gw.reshape(32, 4, 8, 8), w.grad, tol, 2e-3)
+    close(gb, b.grad, tol, 2e-3)
