@@ -27,18 +27,38 @@ __device__ __forceinline__ void u8x16_to_bf16(uint4 v, uint4& lo, uint4& hi) {
     hi = make_uint4(c.x, c.y, d.x, d.y);
 }
 
-// frame stack of image `img` -> bf16 patch in LDS, same linear [c][y][x] order
-__device__ __forceinline__ void load_patch(const uint8_t* frames, const int* idx, long frame_bytes, int img,
-                                           bf16_t* patch, int tid) {
+// The frame stack of an image moves global -> registers (issue()) -> bf16 patch in LDS (commit()), same
+// linear [c][y][x] order.  All loads of an image are issued back to back into a fixed register array
+// (a runtime-trip-count loop that converts and stores after every load serialises 7 memory round trips:
+// 11 us per image in the first version), and they are issued for image i+1 BEFORE image i is
+// multiplied, so their latency hides under the MFMAs.
+#define DY_IT 7         // dy rows of one image: up to 7 * 256 16-byte chunks = 448 output pixels x 32 channels
+#define PATCH_IT 8      // 16-byte loads per thread: frames up to 8 * 256 * 16 = 32 KB
+struct PatchRegs { uint4 v[PATCH_IT]; };
+
+__device__ __forceinline__ void patch_issue(PatchRegs& r, const uint8_t* frames, const int* idx, long frame_bytes,
+                                            int img, int tid) {
     long f = idx ? (long)idx[img] : (long)img;
     const uint4* src = reinterpret_cast<const uint4*>(frames + f * frame_bytes);
     int n16 = (int)(frame_bytes >> 4);
-    for (int t = tid; t < n16; t += 256) {
-        uint4 lo, hi;
-        u8x16_to_bf16(src[t], lo, hi);
-        uint4* dst = reinterpret_cast<uint4*>(patch + (long)t * 16);
-        dst[0] = lo;
-        dst[1] = hi;
+#pragma unroll
+    for (int i = 0; i < PATCH_IT; ++i) {
+        int t = tid + i * 256;
+        r.v[i] = src[t < n16 ? t : 0];      // unconditional: lanes past the end re-read element 0
+    }
+}
+__device__ __forceinline__ void patch_commit(const PatchRegs& r, long frame_bytes, bf16_t* patch, int tid) {
+    int n16 = (int)(frame_bytes >> 4);
+#pragma unroll
+    for (int i = 0; i < PATCH_IT; ++i) {
+        int t = tid + i * 256;
+        if (t < n16) {
+            uint4 lo, hi;
+            u8x16_to_bf16(r.v[i], lo, hi);
+            uint4* dst = reinterpret_cast<uint4*>(patch + (long)t * 16);
+            dst[0] = lo;
+            dst[1] = hi;
+        }
     }
 }
 
@@ -75,10 +95,14 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1FwdArgs a) {
             wf[ks][nb] = *reinterpret_cast<const bf16x8*>(a.w[grp] + (long)(nb * 16 + l15) * K + ks * 32 + g4 * 8);
     const float b0 = a.bias[grp] ? a.bias[grp][l15] : 0.f, b1 = a.bias[grp] ? a.bias[grp][16 + l15] : 0.f;
 
+    PatchRegs pr;
+    if ((int)blockIdx.x < a.batch) patch_issue(pr, a.frames[grp], a.idx[grp], frame_bytes, blockIdx.x, tid);
     for (int img = blockIdx.x; img < a.batch; img += gridDim.x) {
         __syncthreads();                // everyone is done reading the previous patch
-        load_patch(a.frames[grp], a.idx[grp], frame_bytes, img, patch, tid);
+        patch_commit(pr, frame_bytes, patch, tid);
         __syncthreads();
+        if (img + (int)gridDim.x < a.batch)     // next image's loads fly under this image's MFMAs
+            patch_issue(pr, a.frames[grp], a.idx[grp], frame_bytes, img + gridDim.x, tid);
         bf16_t* out = a.out[grp] + (long)img * P * 32;
         for (int rb = wave; rb < nrb; rb += 4) {
             int m = rb * 16 + l15;
@@ -138,15 +162,36 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 
+    PatchRegs pr;
+    uint4 dr[DY_IT];
+    auto dy_issue = [&](int img) {
+        const uint4* dsrc = reinterpret_cast<const uint4*>(a.dy + (long)img * P * 32);
+#pragma unroll
+        for (int i = 0; i < DY_IT; ++i) {
+            int t = tid + i * 256;
+            dr[i] = dsrc[t < P * 4 ? t : 0];
+        }
+    };
+    if ((int)blockIdx.x < a.batch) {
+        patch_issue(pr, a.frames, a.idx, frame_bytes, blockIdx.x, tid);
+        dy_issue(blockIdx.x);
+    }
     for (int img = blockIdx.x; img < a.batch; img += gridDim.x) {
         __syncthreads();
-        load_patch(a.frames, a.idx, frame_bytes, img, patch, tid);
+        patch_commit(pr, frame_bytes, patch, tid);
         // dy rows of this image -> T layout [px][32]: 4 x 16-byte chunks per pixel row, chunk pair j = 2 rg
-        const uint4* dsrc = reinterpret_cast<const uint4*>(a.dy + (long)img * P * 32);
-        for (int t = tid; t < PP * 4; t += 256) {
-            int px = t >> 2, rg = t & 3;
-            uint4 v = px < P ? dsrc[t] : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(dyt + px * 32 + (((2 * rg) ^ swz_t<32>(px)) << 2)) = v;
+#pragma unroll
+        for (int i = 0; i < DY_IT; ++i) {
+            int t = tid + i * 256;
+            if (t < PP * 4) {
+                int px = t >> 2, rg = t & 3;
+                uint4 v = px < P ? dr[i] : make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(dyt + px * 32 + (((2 * rg) ^ swz_t<32>(px)) << 2)) = v;
+            }
+        }
+        if (img + (int)gridDim.x < a.batch) {   // next image's loads fly under this image's MFMAs
+            patch_issue(pr, a.frames, a.idx, frame_bytes, img + gridDim.x, tid);
+            dy_issue(img + gridDim.x);
         }
         for (int ch = 0; ch < nchunk; ++ch) {
             __syncthreads();            // patch / dyt ready (first chunk); previous chunk's col consumed
@@ -204,7 +249,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
 // Does the specialised path cover this conv?  (Nature conv1 on 4-frame stacks)
 PDA_EXPORT int pda_conv1_supported(int H, int W, int C, int KH, int KW, int S, int O) {
     return (C == 4 && KH == 8 && KW == 8 && S == 4 && O == 32 && W % 4 == 0 && ((long)C * H * W) % 16 == 0 &&
-            (long)C * H * W * 2 <= 64 * 1024) ? 1 : 0;
+            (long)C * H * W <= PATCH_IT * 256 * 16 && ((H - 8) / 4 + 1) * ((W - 8) / 4 + 1) <= DY_IT * 64) ? 1 : 0;
 }
 
 PDA_EXPORT void pda_conv1_fwd_u8(const void* const* frames, const void* const* idx, const void* const* w,
