@@ -134,6 +134,7 @@ struct Conv1WgradArgs {
     const uint8_t* frames; const int* idx; const bf16_t* dy;    // dy [(b, oy, ox)][32] bf16
     float* gw; float* gb; long slice_stride, bslice_stride;     // slab slice blockIdx.x
     int batch; Conv1Geom g; float scale;
+    int parts;      // workgroups per image (small batches: the 32-pixel chunks of an image are split)
 };
 
 // LDS: patch [C*H*W] | dyT [PP][32] (T layout, ROWS = 32) | col 4 x [32 px][64 k] (T layout, ROWS = 64)
@@ -172,11 +173,13 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
             dr[i] = dsrc[t < P * 4 ? t : 0];
         }
     };
-    if ((int)blockIdx.x < a.batch) {
-        patch_issue(pr, a.frames, a.idx, frame_bytes, blockIdx.x, tid);
-        dy_issue(blockIdx.x);
+    const int part = blockIdx.x % a.parts, img0 = blockIdx.x / a.parts, img_step = gridDim.x / a.parts;
+    const int ch_beg = part * nchunk / a.parts, ch_end = (part + 1) * nchunk / a.parts;
+    if (img0 < a.batch) {
+        patch_issue(pr, a.frames, a.idx, frame_bytes, img0, tid);
+        dy_issue(img0);
     }
-    for (int img = blockIdx.x; img < a.batch; img += gridDim.x) {
+    for (int img = img0; img < a.batch; img += img_step) {
         __syncthreads();
         patch_commit(pr, frame_bytes, patch, tid);
         // dy rows of this image -> T layout [px][32]: 4 x 16-byte chunks per pixel row, chunk pair j = 2 rg
@@ -189,11 +192,11 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
                 *reinterpret_cast<uint4*>(dyt + px * 32 + (((2 * rg) ^ swz_t<32>(px)) << 2)) = v;
             }
         }
-        if (img + (int)gridDim.x < a.batch) {   // next image's loads fly under this image's MFMAs
-            patch_issue(pr, a.frames, a.idx, frame_bytes, img + gridDim.x, tid);
-            dy_issue(img + gridDim.x);
+        if (img + img_step < a.batch) {         // next image's loads fly under this image's MFMAs
+            patch_issue(pr, a.frames, a.idx, frame_bytes, img + img_step, tid);
+            dy_issue(img + img_step);
         }
-        for (int ch = 0; ch < nchunk; ++ch) {
+        for (int ch = ch_beg; ch < ch_end; ++ch) {
             __syncthreads();            // patch / dyt ready (first chunk); previous chunk's col consumed
             // expand im2col rows of pixels [32 ch, 32 ch + 32): item = (px, j = (c, ky)) -> 8 bf16 (kx 0..7)
             for (int t = tid; t < 32 * (K / 8); t += 256) {
@@ -267,7 +270,11 @@ PDA_EXPORT void pda_conv1_fwd_u8(const void* const* frames, const void* const* i
 }
 
 // Slices the weight-gradient launch writes for this batch (one per workgroup).
-PDA_EXPORT int pda_conv1_wgrad_slices(int batch) { return batch < 256 ? batch : 256; }
+static int conv1_wgrad_parts(int batch) { return batch <= 64 ? 4 : (batch <= 128 ? 2 : 1); }
+PDA_EXPORT int pda_conv1_wgrad_slices(int batch) {
+    int blocks = batch * conv1_wgrad_parts(batch);
+    return blocks < 256 ? blocks : 256;
+}
 
 PDA_EXPORT void pda_conv1_wgrad_u8(const void* dy, const void* frames, const void* idx, void* gw, void* gb,
                                    int batch, int H, int W, int C, float scale, long slice_stride,
@@ -276,6 +283,7 @@ PDA_EXPORT void pda_conv1_wgrad_u8(const void* dy, const void* frames, const voi
     a.frames = (const uint8_t*)frames; a.idx = (const int*)idx; a.dy = (const bf16_t*)dy;
     a.gw = (float*)gw; a.gb = (float*)gb; a.slice_stride = slice_stride; a.bslice_stride = bslice_stride;
     a.batch = batch; a.g = {C, H, W, (H - 8) / 4 + 1, (W - 8) / 4 + 1}; a.scale = scale;
+    a.parts = conv1_wgrad_parts(batch);
     int P = a.g.OH * a.g.OW, PP = (P + 31) / 32 * 32;
     size_t lds = ((size_t)C * H * W + (size_t)PP * 32 + 4 * 32 * 64) * 2;
     static bool attr_set = false;
