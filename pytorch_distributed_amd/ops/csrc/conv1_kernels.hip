@@ -73,6 +73,7 @@ struct Conv1FwdArgs {
     const uint8_t* frames[GEMM_MAX_GROUPS]; const int* idx[GEMM_MAX_GROUPS]; const bf16_t* w[GEMM_MAX_GROUPS];
     const float* bias[GEMM_MAX_GROUPS]; bf16_t* out[GEMM_MAX_GROUPS];
     int batch; Conv1Geom g; float scale; int act;
+    int parts;      // workgroups per image (small batches: an image's 16-pixel row blocks are split)
 };
 
 // grid (blocks, groups); each block loops over images blockIdx.x, += gridDim.x
@@ -96,15 +97,17 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1FwdArgs a) {
     const float b0 = a.bias[grp] ? a.bias[grp][l15] : 0.f, b1 = a.bias[grp] ? a.bias[grp][16 + l15] : 0.f;
 
     PatchRegs pr;
-    if ((int)blockIdx.x < a.batch) patch_issue(pr, a.frames[grp], a.idx[grp], frame_bytes, blockIdx.x, tid);
-    for (int img = blockIdx.x; img < a.batch; img += gridDim.x) {
+    const int part = blockIdx.x % a.parts, img0 = blockIdx.x / a.parts, img_step = gridDim.x / a.parts;
+    const int rb_beg = part * nrb / a.parts, rb_end = (part + 1) * nrb / a.parts;
+    if (img0 < a.batch) patch_issue(pr, a.frames[grp], a.idx[grp], frame_bytes, img0, tid);
+    for (int img = img0; img < a.batch; img += img_step) {
         __syncthreads();                // everyone is done reading the previous patch
         patch_commit(pr, frame_bytes, patch, tid);
         __syncthreads();
-        if (img + (int)gridDim.x < a.batch)     // next image's loads fly under this image's MFMAs
-            patch_issue(pr, a.frames[grp], a.idx[grp], frame_bytes, img + gridDim.x, tid);
+        if (img + img_step < a.batch)           // next image's loads fly under this image's MFMAs
+            patch_issue(pr, a.frames[grp], a.idx[grp], frame_bytes, img + img_step, tid);
         bf16_t* out = a.out[grp] + (long)img * P * 32;
-        for (int rb = wave; rb < nrb; rb += 4) {
+        for (int rb = rb_beg + wave; rb < rb_end; rb += 4) {
             int m = rb * 16 + l15;
             int mm = m < P ? m : 0;
             int oy = mm / g.OW, ox = mm - oy * g.OW;
@@ -264,7 +267,8 @@ PDA_EXPORT void pda_conv1_fwd_u8(const void* const* frames, const void* const* i
         a.bias[i] = (const float*)bias[i]; a.out[i] = (bf16_t*)out[i];
     }
     a.batch = batch; a.g = {C, H, W, (H - 8) / 4 + 1, (W - 8) / 4 + 1}; a.scale = scale; a.act = act;
-    int blocks = batch < 512 ? batch : 512;     // 2 resident per CU (56 KB LDS each)
+    a.parts = batch * ngroups <= 128 ? 4 : (batch * ngroups <= 256 ? 2 : 1);
+    int blocks = batch * a.parts < 512 ? batch * a.parts : 512;     // 2 resident per CU (56 KB LDS each)
     size_t lds = (size_t)C * H * W * 2;
     hipLaunchKernelGGL(conv1_fwd_kernel<4>, dim3(blocks, ngroups), dim3(256), lds, stream, a);
 }
