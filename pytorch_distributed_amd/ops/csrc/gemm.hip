@@ -4,6 +4,7 @@
 // learner steps into a hipGraph.
 #include "gemm.h"
 #include "api.h"
+#include <cstdlib>
 
 namespace {
 
@@ -23,6 +24,13 @@ PDA_EXPORT void pda_conv_fwd_u8(const void* const* frames, const void* const* id
                                 const void* const* bias, void* const* out, int ngroups, int batch,
                                 int H, int W, int C, int KH, int KW, int S, int O, float scale, int act,
                                 hipStream_t stream) {
+    // Nature conv1 geometry: the whole-image kernel (conv1_kernels.hip); PDA_CONV1_GENERIC=1 keeps this loader
+    const char* env = getenv("PDA_CONV1_GENERIC");
+    const bool generic_only = env && env[0] == '1';
+    if (!generic_only && ngroups <= GEMM_MAX_GROUPS && pda_conv1_supported(H, W, C, KH, KW, S, O)) {
+        pda_conv1_fwd_u8(frames, idx, w, bias, out, ngroups, batch, H, W, C, scale, act, stream);
+        return;
+    }
     ConvGeom g = make_geom(H, W, C, KH, KW, S);
     int M = batch * g.OH * g.OW, K = C * KH * KW;
     GemmArgs<SrcFrameU8K, SrcDenseK, EpiBiasAct> a;

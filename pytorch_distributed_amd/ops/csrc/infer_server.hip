@@ -120,7 +120,7 @@ void enqueue_program(Server& S, int n) {
         pda_conv_fwd(x2, w2, b2, o3, 1, n, H2, W2, 64, 3, 3, 1, 64, ACT_RELU, st);
         // fc1 split-K into the fp32 pre-activation buffer (the head zeroes it again after reading)
         int tiles = ((n + 63) / 64) * (c.HID / 64);
-        int slices = 768 / (tiles > 0 ? tiles : 1);
+        int slices = 256 / (tiles > 0 ? tiles : 1);    // measured best for the learner's fc1 too (fewer fp32 atomics)
         if (slices < 1) slices = 1;
         int ks = (F + slices - 1) / slices;
         ks = (ks + 31) / 32 * 32;

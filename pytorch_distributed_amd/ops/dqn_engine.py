@@ -226,6 +226,10 @@ class _Acts(object):
                 self.dcol2 = z(B * g.H2 * g.W2, g.K2)
 
 
+_WGRAD_BLOCKS = int(os.environ.get("PDA_WGRAD_BLOCKS", "256"))  # split-K target for the conv weight gradients
+_FC1_BLOCKS = int(os.environ.get("PDA_FC1_BLOCKS", "256"))     # split-K target for fc1 forward (blocks per launch)
+
+
 def cnn_forward(geom, nets, frames, idxs, acts, B, norm_val):
     """Run len(nets) (<= 3) networks as problem groups of the same launches.
     Leaves fc1's pre-activation split-K sums in acts.h1pre[g] (which must be zero)."""
@@ -236,7 +240,7 @@ def cnn_forward(geom, nets, frames, idxs, acts, B, norm_val):
     nn.conv_fwd(acts.a2[:n], [w.w[2] for w in nets], [w.b[2] for w in nets], acts.a3[:n], B, g.H2, g.W2, 64, 3, 3, 1, 64)
     tiles = ((B + 63) // 64) * (g.HID // 64) * n
     nn.linear_fwd(acts.a3[:n], [w.w[3] for w in nets], None, None, acts.h1pre[:n], B, g.HID, g.F, g.F, g.F,
-                  0, g.HID, ksplit=_ksplit(g.F, tiles, 768, 128))
+                  0, g.HID, ksplit=_ksplit(g.F, tiles, _FC1_BLOCKS, 128))
 
 
 class DqnCnnEngine(object):
@@ -293,7 +297,7 @@ class DqnCnnEngine(object):
         for li, (O, K, red) in enumerate([(32, g.K1, B * g.H1 * g.W1), (64, g.K2, B * g.H2 * g.W2),
                                           (64, g.K3, B * g.P3)]):
             tiles = ((O + 63) // 64 if O > 32 else 1) * ((K + 63) // 64)
-            ks = _ksplit(red, tiles, 512, 128)
+            ks = _ksplit(red, tiles, _WGRAD_BLOCKS, 128)
             ns = nn.num_slices(red, ks)
             if li == 0 and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32):
                 ns = nn.conv1_wgrad_slices(B)       # whole-image kernel: one slice per workgroup
