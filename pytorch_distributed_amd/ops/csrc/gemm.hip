@@ -16,6 +16,13 @@ ConvGeom make_geom(int H, int W, int C, int KH, int KW, int S) {
     return g;
 }
 
+// fewer 64x64 tiles than CUs on the chip: halve the tile so that twice the workgroups share the work
+bool small_grid(int M, int N, int groups) {
+    long tiles = (long)((M + 63) / 64) * ((N + 63) / 64) * groups;
+    static const bool off = [] { const char* e = getenv("PDA_NO_SMALL_TILES"); return e && e[0] == '1'; }();
+    return !off && tiles < 224;
+}
+
 }  // namespace
 
 // ---- conv1 forward: uint8 planar frames (optionally gathered through idx) ----------
@@ -58,6 +65,7 @@ PDA_EXPORT void pda_conv_fwd(const void* const* x, const void* const* w, const v
         a.g[i].M = M; a.g[i].N = O; a.g[i].K = K;
     }
     if (O <= 32) launch_gemm<64, 32, 4, 1>(a, ngroups, M, O, K, 0, stream);
+    else if (small_grid(M, O, ngroups)) launch_gemm<32, 64, 1, 4>(a, ngroups, M, O, K, 0, stream);
     else launch_gemm<64, 64, 2, 2>(a, ngroups, M, O, K, 0, stream);
 }
 
@@ -99,7 +107,8 @@ PDA_EXPORT void pda_linear_dgrad(const void* dy, const void* w, const void* y, v
     a.g[0].b = {(const bf16_t*)w, ldw, Kin, Nout};          // element(row=kin, red=nout) = w[nout*ldw + kin]
     a.g[0].e = {(bf16_t*)dx, (const bf16_t*)y, y ? act : ACT_NONE, lddx, ldy};
     a.g[0].M = M; a.g[0].N = Kin; a.g[0].K = Nout;
-    if (M <= 32) launch_gemm<32, 64, 1, 4>(a, 1, M, Kin, Nout, 0, stream);
+    // under-filled launches (fc1 dgrad at batch 128: 98 tiles of 64x64 for 256 CUs) take the 32-row tile
+    if (M <= 32 || small_grid(M, Kin, 1)) launch_gemm<32, 64, 1, 4>(a, 1, M, Kin, Nout, 0, stream);
     else launch_gemm<64, 64, 2, 2>(a, 1, M, Kin, Nout, 0, stream);
 }
 
