@@ -36,3 +36,9 @@ PDA_EXPORT int pda_conv1_supported(int H, int W, int C, int KH, int KW, int S, i
 PDA_EXPORT void pda_conv1_fwd_u8(const void* const* frames, const void* const* idx, const void* const* w,
                                  const void* const* bias, void* const* out, int ngroups, int batch, int H, int W,
                                  int C, float scale, int act, hipStream_t stream);
+PDA_EXPORT int pda_cnn_fwd_stack_supported(int H, int W, int C);
+PDA_EXPORT void pda_cnn_fwd_stack(const void* const* frames, const void* const* idx, const void* const* w1,
+                                  const void* const* b1, const void* const* w2, const void* const* b2,
+                                  const void* const* w3, const void* const* b3, void* const* a1, void* const* a2,
+                                  void* const* a3, int ngroups, int batch, int H, int W, int C, float scale,
+                                  hipStream_t stream);

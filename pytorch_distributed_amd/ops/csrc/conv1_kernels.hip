@@ -250,6 +250,142 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
     }
 }
 
+// ---- whole forward conv stack per image: conv1 -> conv2 (4x4 s2, 64) -> conv3 (3x3 s1, 64) -------------
+// At batch 128 the three conv forwards are three under-filled launches of latency-bound k-loops
+// (11 + 12 + 12 us).  Here one workgroup carries an image through all three layers with every
+// intermediate in LDS: the frame patch (bf16), a1 [OH1*OW1][32] and a2 [OH2*OW2][64] (row pitches
+// padded to 5 and 9 sixteen-byte slots so that the strided pixel rows an MFMA A-fragment gathers fall on
+// different banks), all weights as register-resident B-fragments (64 + 64 + 72 VGPRs; wave w owns
+// output-channel block w of conv2 / conv3), a3 and -- for the network that is trained -- a1 / a2
+// written out with coalesced copies.  Nothing but the frames is read from HBM.
+struct FwdStackArgs {
+    const uint8_t* frames[GEMM_MAX_GROUPS]; const int* idx[GEMM_MAX_GROUPS];
+    const bf16_t* w1[GEMM_MAX_GROUPS]; const float* b1[GEMM_MAX_GROUPS];
+    const bf16_t* w2[GEMM_MAX_GROUPS]; const float* b2[GEMM_MAX_GROUPS];
+    const bf16_t* w3[GEMM_MAX_GROUPS]; const float* b3[GEMM_MAX_GROUPS];
+    bf16_t* a1[GEMM_MAX_GROUPS]; bf16_t* a2[GEMM_MAX_GROUPS]; bf16_t* a3[GEMM_MAX_GROUPS];   // a1 / a2 may be null
+    int batch; Conv1Geom g; float scale;
+};
+
+#define A1_PITCH 40     // bf16 elements per a1 pixel row in LDS (32 channels + 8 pad = 5 slots)
+#define A2_PITCH 72     // 64 channels + 8 pad = 9 slots
+
+__global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    constexpr int C = 4, KS1 = 8, KS2 = 16, KS3 = 18;
+    const int grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const Conv1Geom g = a.g;
+    const int OH1 = g.OH, OW1 = g.OW, P1 = OH1 * OW1;                   // 20 x 20
+    const int OH2 = (OH1 - 4) / 2 + 1, OW2 = (OW1 - 4) / 2 + 1, P2 = OH2 * OW2;   // 9 x 9
+    const int OH3 = OH2 - 2, OW3 = OW2 - 2, P3 = OH3 * OW3;             // 7 x 7
+    const long frame_bytes = (long)C * g.H * g.W;
+    bf16_t* patch = lds;
+    bf16_t* a1s = lds + frame_bytes;
+    bf16_t* a2s = lds;                      // reuses the patch region once conv1 is done
+
+    // weights -> B fragments (lane: n = l15 + 16 nb, k = 32 ks + 8 g4 .. +7)
+    bf16x8 wf1[KS1][2], wf2[KS2], wf3[KS3];
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+            wf1[ks][nb] = *reinterpret_cast<const bf16x8*>(a.w1[grp] + (long)(nb * 16 + l15) * 256 + ks * 32 + g4 * 8);
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks)
+        wf2[ks] = *reinterpret_cast<const bf16x8*>(a.w2[grp] + (long)(wave * 16 + l15) * 512 + ks * 32 + g4 * 8);
+#pragma unroll
+    for (int ks = 0; ks < KS3; ++ks)
+        wf3[ks] = *reinterpret_cast<const bf16x8*>(a.w3[grp] + (long)(wave * 16 + l15) * 576 + ks * 32 + g4 * 8);
+    const float b10 = a.b1[grp][l15], b11 = a.b1[grp][16 + l15];
+    const float b2v = a.b2[grp][wave * 16 + l15], b3v = a.b3[grp][wave * 16 + l15];
+
+    PatchRegs pr;
+    if ((int)blockIdx.x < a.batch) patch_issue(pr, a.frames[grp], a.idx[grp], frame_bytes, blockIdx.x, tid);
+    for (int img = blockIdx.x; img < a.batch; img += gridDim.x) {
+        __syncthreads();                    // previous image fully consumed (a2s aliases the patch)
+        patch_commit(pr, frame_bytes, patch, tid);
+        __syncthreads();
+        if (img + (int)gridDim.x < a.batch)
+            patch_issue(pr, a.frames[grp], a.idx[grp], frame_bytes, img + gridDim.x, tid);
+
+        // ---- conv1: 8x8 s4, 32 channels -> a1s
+        for (int rb = wave; rb < (P1 + 15) / 16; rb += 4) {
+            int m = rb * 16 + l15;
+            int mm = m < P1 ? m : 0;
+            int oy = mm / OW1, ox = mm - oy * OW1;
+            const bf16_t* base = patch + (4 * oy) * g.W + 4 * ox;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                int c = ks >> 1, ky = (ks & 1) * 4 + g4;
+                bf16x8 af = patch_frag(base + (long)c * g.H * g.W + ky * g.W);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf1[ks][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf1[ks][1], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int pix = rb * 16 + g4 * 4 + r;
+                if (pix < P1) {
+                    a1s[pix * A1_PITCH + l15] = f2bf(fmaxf(acc0[r] * a.scale + b10, 0.f));
+                    a1s[pix * A1_PITCH + 16 + l15] = f2bf(fmaxf(acc1[r] * a.scale + b11, 0.f));
+                }
+            }
+        }
+        __syncthreads();                    // a1 complete; the patch is dead from here on
+        if (a.a1[grp]) {                    // coalesced copy-out for the backward pass (4 x 16 B per pixel)
+            uint4* dst = reinterpret_cast<uint4*>(a.a1[grp] + (long)img * P1 * 32);
+            for (int t = tid; t < P1 * 4; t += 256)
+                dst[t] = *reinterpret_cast<const uint4*>(a1s + (t >> 2) * A1_PITCH + (t & 3) * 8);
+        }
+        // ---- conv2: 4x4 s2, 32 -> 64; wave w computes output channels [16 w, 16 w + 16) -> a2s
+        for (int rb = 0; rb < (P2 + 15) / 16; ++rb) {
+            int m = rb * 16 + l15;
+            int mm = m < P2 ? m : 0;
+            int oy = mm / OW2, ox = mm - oy * OW2;
+            const bf16_t* base = a1s + ((2 * oy) * OW1 + 2 * ox) * A1_PITCH + g4 * 8;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {      // one tap (ky, kx) = 32 channels per k-step
+                int ky = ks >> 2, kx = ks & 3;
+                bf16x8 af = *reinterpret_cast<const bf16x8*>(base + (ky * OW1 + kx) * A1_PITCH);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf2[ks], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int pix = rb * 16 + g4 * 4 + r;
+                if (pix < P2) a2s[pix * A2_PITCH + wave * 16 + l15] = f2bf(fmaxf(acc[r] + b2v, 0.f));
+            }
+        }
+        __syncthreads();                    // a2 complete
+        if (a.a2[grp]) {
+            uint4* dst = reinterpret_cast<uint4*>(a.a2[grp] + (long)img * P2 * 64);
+            for (int t = tid; t < P2 * 8; t += 256)
+                dst[t] = *reinterpret_cast<const uint4*>(a2s + (t >> 3) * A2_PITCH + (t & 7) * 8);
+        }
+        // ---- conv3: 3x3 s1, 64 -> 64 -> global a3 [(img, pix)][64]
+        bf16_t* out3 = a.a3[grp] + (long)img * P3 * 64;
+        for (int rb = 0; rb < (P3 + 15) / 16; ++rb) {
+            int m = rb * 16 + l15;
+            int mm = m < P3 ? m : 0;
+            int oy = mm / OW3, ox = mm - oy * OW3;
+            const bf16_t* base = a2s + (oy * OW2 + ox) * A2_PITCH + g4 * 8;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS3; ++ks) {      // tap = ks / 2, channel half = ks % 2
+                int tap = ks >> 1, ky = tap / 3, kx = tap - 3 * ky;
+                bf16x8 af = *reinterpret_cast<const bf16x8*>(base + (ky * OW2 + kx) * A2_PITCH + (ks & 1) * 32);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf3[ks], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int pix = rb * 16 + g4 * 4 + r;
+                if (pix < P3) out3[(long)pix * 64 + wave * 16 + l15] = f2bf(fmaxf(acc[r] + b3v, 0.f));
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // Does the specialised path cover this conv?  (Nature conv1 on 4-frame stacks)
@@ -297,4 +433,40 @@ PDA_EXPORT void pda_conv1_wgrad_u8(const void* dy, const void* frames, const voi
         attr_set = true;
     }
     hipLaunchKernelGGL(conv1_wgrad_kernel<4>, dim3(pda_conv1_wgrad_slices(batch)), dim3(256), lds, stream, a);
+}
+
+// conv1 -> conv2 -> conv3 forward of the Nature CNN in one launch (relu after each; see cnn_fwd_stack_kernel).
+// Layer shapes are the Nature ones: 8x8 s4 x32, 4x4 s2 x64, 3x3 s1 x64 on C = 4 frame stacks.
+PDA_EXPORT int pda_cnn_fwd_stack_supported(int H, int W, int C) {
+    if (!pda_conv1_supported(H, W, C, 8, 8, 4, 32)) return 0;
+    int OH1 = (H - 8) / 4 + 1, OW1 = (W - 8) / 4 + 1;
+    if (OH1 < 8 || OW1 < 8) return 0;
+    size_t lds = ((size_t)C * H * W + (size_t)OH1 * OW1 * A1_PITCH) * 2;
+    int OH2 = (OH1 - 4) / 2 + 1, OW2 = (OW1 - 4) / 2 + 1;
+    return (lds <= 150 * 1024 && (size_t)OH2 * OW2 * A2_PITCH <= (size_t)C * H * W) ? 1 : 0;
+}
+
+PDA_EXPORT void pda_cnn_fwd_stack(const void* const* frames, const void* const* idx, const void* const* w1,
+                                  const void* const* b1, const void* const* w2, const void* const* b2,
+                                  const void* const* w3, const void* const* b3, void* const* a1, void* const* a2,
+                                  void* const* a3, int ngroups, int batch, int H, int W, int C, float scale,
+                                  hipStream_t stream) {
+    FwdStackArgs a;
+    for (int i = 0; i < ngroups; ++i) {
+        a.frames[i] = (const uint8_t*)frames[i]; a.idx[i] = (const int*)idx[i];
+        a.w1[i] = (const bf16_t*)w1[i]; a.b1[i] = (const float*)b1[i];
+        a.w2[i] = (const bf16_t*)w2[i]; a.b2[i] = (const float*)b2[i];
+        a.w3[i] = (const bf16_t*)w3[i]; a.b3[i] = (const float*)b3[i];
+        a.a1[i] = (bf16_t*)a1[i]; a.a2[i] = (bf16_t*)a2[i]; a.a3[i] = (bf16_t*)a3[i];
+    }
+    a.batch = batch; a.g = {C, H, W, (H - 8) / 4 + 1, (W - 8) / 4 + 1}; a.scale = scale;
+    size_t lds = ((size_t)C * H * W + (size_t)a.g.OH * a.g.OW * A1_PITCH) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_fwd_stack_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    int blocks = batch < 256 ? batch : 256;         // one workgroup per CU (88 KB LDS), looping over images
+    hipLaunchKernelGGL(cnn_fwd_stack_kernel, dim3(blocks, ngroups), dim3(256), lds, stream, a);
 }

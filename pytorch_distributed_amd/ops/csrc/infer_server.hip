@@ -24,6 +24,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -115,9 +116,16 @@ void enqueue_program(Server& S, int n) {
         void* o1[1] = {S.a1}; void* o2[1] = {S.a2}; void* o3[1] = {S.a3};
         const void* x1[1] = {S.a1}; const void* x2[1] = {S.a2}; const void* x3[1] = {S.a3};
         void* o32[1] = {S.h1pre};
-        pda_conv_fwd_u8(frames, idx, w0, b0, o1, 1, n, c.H, c.W, c.C, 8, 8, 4, 32, c.inv_norm, ACT_RELU, st);
-        pda_conv_fwd(x1, w1, b1, o2, 1, n, H1, W1, 32, 4, 4, 2, 64, ACT_RELU, st);
-        pda_conv_fwd(x2, w2, b2, o3, 1, n, H2, W2, 64, 3, 3, 1, 64, ACT_RELU, st);
+        const char* nofuse = getenv("PDA_FUSED_FWD");
+        if (pda_cnn_fwd_stack_supported(c.H, c.W, c.C) && !(nofuse && nofuse[0] == '0')) {
+            // the three conv layers in one launch, intermediates in LDS (conv1_kernels.hip)
+            void* none[1] = {nullptr};
+            pda_cnn_fwd_stack(frames, idx, w0, b0, w1, b1, w2, b2, none, none, o3, 1, n, c.H, c.W, c.C, c.inv_norm, st);
+        } else {
+            pda_conv_fwd_u8(frames, idx, w0, b0, o1, 1, n, c.H, c.W, c.C, 8, 8, 4, 32, c.inv_norm, ACT_RELU, st);
+            pda_conv_fwd(x1, w1, b1, o2, 1, n, H1, W1, 32, 4, 4, 2, 64, ACT_RELU, st);
+            pda_conv_fwd(x2, w2, b2, o3, 1, n, H2, W2, 64, 3, 3, 1, 64, ACT_RELU, st);
+        }
         // fc1 split-K into the fp32 pre-activation buffer (the head zeroes it again after reading)
         int tiles = ((n + 63) / 64) * (c.HID / 64);
         int slices = 256 / (tiles > 0 ? tiles : 1);    // measured best for the learner's fc1 too (fewer fp32 atomics)

@@ -230,14 +230,23 @@ _WGRAD_BLOCKS = int(os.environ.get("PDA_WGRAD_BLOCKS", "256"))  # split-K target
 _FC1_BLOCKS = int(os.environ.get("PDA_FC1_BLOCKS", "256"))     # split-K target for fc1 forward (blocks per launch)
 
 
-def cnn_forward(geom, nets, frames, idxs, acts, B, norm_val):
+def cnn_forward(geom, nets, frames, idxs, acts, B, norm_val, keep_first_only=True):
     """Run len(nets) (<= 3) networks as problem groups of the same launches.
     Leaves fc1's pre-activation split-K sums in acts.h1pre[g] (which must be zero)."""
     g, n = geom, len(nets)
-    nn.conv_fwd_u8(frames, idxs, [w.w[0] for w in nets], [w.b[0] for w in nets], acts.a1[:n], B,
-                   g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / float(norm_val))
-    nn.conv_fwd(acts.a1[:n], [w.w[1] for w in nets], [w.b[1] for w in nets], acts.a2[:n], B, g.H1, g.W1, 32, 4, 4, 2, 64)
-    nn.conv_fwd(acts.a2[:n], [w.w[2] for w in nets], [w.b[2] for w in nets], acts.a3[:n], B, g.H2, g.W2, 64, 3, 3, 1, 64)
+    if nn.cnn_fwd_stack_supported(g.H, g.W, g.C):
+        # one launch, one workgroup per image; only group 0 (the trained network on s0) keeps a1 / a2
+        keep = [True] + [False] * (n - 1) if keep_first_only else [True] * n
+        nn.cnn_fwd_stack(frames, idxs, [w.w[0] for w in nets], [w.b[0] for w in nets],
+                         [w.w[1] for w in nets], [w.b[1] for w in nets], [w.w[2] for w in nets],
+                         [w.b[2] for w in nets], [acts.a1[i] if keep[i] else None for i in range(n)],
+                         [acts.a2[i] if keep[i] else None for i in range(n)], acts.a3[:n], B, g.H, g.W, g.C,
+                         1.0 / float(norm_val))
+    else:
+        nn.conv_fwd_u8(frames, idxs, [w.w[0] for w in nets], [w.b[0] for w in nets], acts.a1[:n], B,
+                       g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / float(norm_val))
+        nn.conv_fwd(acts.a1[:n], [w.w[1] for w in nets], [w.b[1] for w in nets], acts.a2[:n], B, g.H1, g.W1, 32, 4, 4, 2, 64)
+        nn.conv_fwd(acts.a2[:n], [w.w[2] for w in nets], [w.b[2] for w in nets], acts.a3[:n], B, g.H2, g.W2, 64, 3, 3, 1, 64)
     tiles = ((B + 63) // 64) * (g.HID // 64) * n
     nn.linear_fwd(acts.a3[:n], [w.w[3] for w in nets], None, None, acts.h1pre[:n], B, g.HID, g.F, g.F, g.F,
                   0, g.HID, ksplit=_ksplit(g.F, tiles, _FC1_BLOCKS, 128))

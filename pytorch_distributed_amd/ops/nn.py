@@ -61,6 +61,10 @@ def _L():
         L.pda_conv1_wgrad_slices.restype = c_int
         L.pda_conv1_wgrad_u8.argtypes = [_vp] * 5 + [c_int] * 4 + [c_float, c_long, c_long, _vp]
         L.pda_conv1_wgrad_u8.restype = None
+        L.pda_cnn_fwd_stack_supported.argtypes = [c_int] * 3
+        L.pda_cnn_fwd_stack_supported.restype = c_int
+        L.pda_cnn_fwd_stack.argtypes = [_vp] * 11 + [c_int] * 5 + [c_float, _vp]
+        L.pda_cnn_fwd_stack.restype = None
         L.pda_linear_wgrad2.argtypes = [_vp] * 4 + [c_int] + [_vp] * 5 + [_vp]
         L.pda_linear_wgrad2.restype = None
         L.pda_conv_dgrad.argtypes = [_vp] * 4 + [c_int] * 9 + [_vp]
@@ -81,6 +85,21 @@ def conv1_specialised(H, W, C, KH, KW, S, O):
     """True when the whole-image conv1 kernels (csrc/conv1_kernels.hip) cover this layer."""
     import os
     return os.environ.get("PDA_CONV1_GENERIC", "0") != "1" and bool(_L().pda_conv1_supported(H, W, C, KH, KW, S, O))
+
+
+def cnn_fwd_stack_supported(H, W, C):
+    """True when the one-launch conv1 -> conv2 -> conv3 forward (csrc/conv1_kernels.hip) covers this input."""
+    import os
+    return os.environ.get("PDA_FUSED_FWD", "1") != "0" and conv1_specialised(H, W, C, 8, 8, 4, 32) \
+        and bool(_L().pda_cnn_fwd_stack_supported(H, W, C))
+
+
+def cnn_fwd_stack(frames, idx, w1, b1, w2, b2, w3, b3, a1, a2, a3, batch, H, W, C, scale):
+    """Nature-CNN conv stack forward, one workgroup per image, every intermediate in LDS.  Lists with one
+    entry per problem group (<= 4); a1 / a2 entries may be None (activations not needed for a backward)."""
+    n = len(frames)
+    _L().pda_cnn_fwd_stack(_arr(frames), _arr(idx), _arr(w1), _arr(b1), _arr(w2), _arr(b2), _arr(w3), _arr(b3),
+                           _arr(a1), _arr(a2), _arr(a3), n, batch, H, W, C, float(scale), _stream())
 
 
 def conv1_wgrad_slices(batch):

@@ -194,3 +194,41 @@ def test_conv1_wgrad_u8(nn, batch, generic, monkeypatch):
     tol = 2e-3 * max(1.0, batch / 8) ** 0.5
     close(gw.reshape(32, 4, 8, 8), w.grad, tol, 2e-3)
     close(gb, b.grad, tol, 2e-3)
+
+
+@pytest.mark.parametrize("batch,groups", [(5, 1), (128, 2), (300, 3)])
+def test_cnn_fwd_stack_matches_layerwise(nn, batch, groups):
+    """conv1 -> conv2 -> conv3 in ONE launch (intermediates in LDS) == fp32 torch convs, and the a1 / a2
+    copy-outs of the kept group match too; 300 images > 256 workgroups exercises the per-block image loop."""
+    if not nn.cnn_fwd_stack_supported(84, 84, 4):
+        pytest.skip("fused forward not available")
+    torch.manual_seed(9)
+    mem = torch.randint(0, 256, (64, 4, 84, 84), dtype=torch.uint8, device="cuda")
+    idxs, ws, outs = [], [], []
+    for gi in range(groups):
+        idx = torch.randint(0, 64, (batch,), dtype=torch.int32, device="cuda")
+        w1 = bf(torch.randn(32, 4, 8, 8, device="cuda") / 16)
+        w2 = bf(torch.randn(64, 32, 4, 4, device="cuda") / 22)
+        w3 = bf(torch.randn(64, 64, 3, 3, device="cuda") / 24)
+        b1, b2, b3 = (torch.randn(n, device="cuda") * 0.1 for n in (32, 64, 64))
+        idxs.append(idx)
+        ws.append((w1, b1, w2, b2, w3, b3))
+        keep = gi == 0
+        outs.append((torch.zeros(batch * 400, 32, dtype=torch.bfloat16, device="cuda") if keep else None,
+                     torch.zeros(batch * 81, 64, dtype=torch.bfloat16, device="cuda") if keep else None,
+                     torch.zeros(batch * 49, 64, dtype=torch.bfloat16, device="cuda")))
+    nn.cnn_fwd_stack([mem] * groups, idxs,
+                     [w[0].reshape(32, -1).bfloat16().contiguous() for w in ws], [w[1] for w in ws],
+                     [nn.pack_conv_weight(w[2]) for w in ws], [w[3] for w in ws],
+                     [nn.pack_conv_weight(w[4]) for w in ws], [w[5] for w in ws],
+                     [o[0] for o in outs], [o[1] for o in outs], [o[2] for o in outs], batch, 84, 84, 4, 1.0 / 255.0)
+    for gi in range(groups):
+        w1, b1, w2, b2, w3, b3 = ws[gi]
+        x = mem[idxs[gi].long()].float() / 255.0
+        r1 = bf(F.relu(F.conv2d(x, w1, b1, stride=4)))
+        r2 = bf(F.relu(F.conv2d(r1, w2, b2, stride=2)))
+        r3 = F.relu(F.conv2d(r2, w3, b3, stride=1))
+        close(nn.from_nhwc(outs[gi][2], batch, 7, 7, 64), r3, 3e-2, 3e-2)
+        if outs[gi][0] is not None:
+            close(nn.from_nhwc(outs[gi][0], batch, 20, 20, 32), r1)
+            close(nn.from_nhwc(outs[gi][1], batch, 9, 9, 64), r2, 3e-2, 3e-2)
