@@ -386,6 +386,146 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
     }
 }
 
+// ---- data-gradient chain per image: da3 -> (conv3^T, relu'(a2)) -> da2 -> (conv2^T, relu'(a1)) -> da1 -----
+// Replaces four launches of the layer-wise backward (two "dcol" GEMMs writing [pixels][taps x channels]
+// matrices and two col2im gathers reading them back: 34 us of the 141 us step at batch 128, 0.9 GB of
+// scratch at batch 4096).  One workgroup carries an image: da3, the forward activations a2 / a1 (relu
+// masks) and the intermediate da2 live in LDS; the gradients replace the activations in place and leave
+// with coalesced copies.  Both layers are gather-form GEMMs over the taps (conv2: per input-pixel parity
+// class, one class per wave).  The forward weight shadows w[o][(ky,kx,c)] are staged ONCE per workgroup
+// through LDS as per-tap [o][c] tiles and picked up with the transposing ds_read_b64_tr_b16 as
+// B-fragments (rows = c, k = o) that stay in registers for every image of the workgroup.
+struct DgradStackArgs {
+    const bf16_t* da3; const bf16_t* a2; const bf16_t* a1; const bf16_t* w3; const bf16_t* w2;
+    bf16_t* da2; bf16_t* da1; int batch;
+};
+
+__global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    constexpr int P1 = 400, W1 = 20, P2 = 81, W2 = 9, P3 = 49, W3 = 7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, l15 = lane & 15;
+
+    // ---- weights: per-tap [o][c] tiles (T layout) -> B fragments
+    bf16x8 wf3[18];         // conv3^T: this wave's 16 input channels (nb = wave); k-step = (tap, o half)
+    bf16x8 wf2[8][2];       // conv2^T: this wave's parity class; (tap a,b ; o half) x 2 channel blocks
+    for (int t = tid; t < 9 * 64 * 8; t += 256) {
+        int rg = t & 7, o = (t >> 3) & 63, tap = t >> 9;
+        uint4 v = *reinterpret_cast<const uint4*>(a.w3 + (long)o * 576 + tap * 64 + rg * 8);
+        *reinterpret_cast<uint4*>(lds + tap * 4096 + o * 64 + (((2 * rg) ^ swz_t<64>(o)) << 2)) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks)
+        wf3[ks] = read_frag<true, 64, 32>(lds + (ks >> 1) * 4096, wave * 16, ks & 1, lane);
+    __syncthreads();
+    for (int t = tid; t < 16 * 64 * 4; t += 256) {
+        int rg = t & 3, o = (t >> 2) & 63, tap = t >> 8;
+        uint4 v = *reinterpret_cast<const uint4*>(a.w2 + (long)o * 512 + tap * 32 + rg * 8);
+        *reinterpret_cast<uint4*>(lds + tap * 2048 + o * 32 + (((2 * rg) ^ swz_t<32>(o)) << 2)) = v;
+    }
+    __syncthreads();
+    const int py = wave >> 1, px = wave & 1;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {       // t = (a * 2 + b) * 2 + half
+        int ta = t >> 2, tb = (t >> 1) & 1, half = t & 1;
+        int tap = (py + 2 * ta) * 4 + (px + 2 * tb);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) wf2[t][nb] = read_frag<true, 32, 32>(lds + tap * 2048, nb * 16, half, lane);
+    }
+    __syncthreads();
+
+    bf16_t* a1m = lds;                              // [P1][A1_PITCH]   a1, then da1 in place
+    bf16_t* a2m = a1m + P1 * A1_PITCH;              // [P2 + 1][A2_PITCH] a2, then da2 in place; row P2 stays zero
+    bf16_t* d3 = a2m + (P2 + 1) * A2_PITCH;         // [P3 + 1][A2_PITCH] da3; row P3 stays zero
+    for (int t = tid; t < A2_PITCH; t += 256) {
+        a2m[P2 * A2_PITCH + t] = 0;
+        d3[P3 * A2_PITCH + t] = 0;
+    }
+
+    for (int img = blockIdx.x; img < a.batch; img += gridDim.x) {
+        __syncthreads();
+        {
+            const uint4* s1 = reinterpret_cast<const uint4*>(a.a1 + (long)img * P1 * 32);
+            for (int t = tid; t < P1 * 4; t += 256)
+                *reinterpret_cast<uint4*>(a1m + (t >> 2) * A1_PITCH + (t & 3) * 8) = s1[t];
+            const uint4* s2 = reinterpret_cast<const uint4*>(a.a2 + (long)img * P2 * 64);
+            for (int t = tid; t < P2 * 8; t += 256)
+                *reinterpret_cast<uint4*>(a2m + (t >> 3) * A2_PITCH + (t & 7) * 8) = s2[t];
+            const uint4* s3 = reinterpret_cast<const uint4*>(a.da3 + (long)img * P3 * 64);
+            for (int t = tid; t < P3 * 8; t += 256)
+                *reinterpret_cast<uint4*>(d3 + (t >> 3) * A2_PITCH + (t & 7) * 8) = s3[t];
+        }
+        __syncthreads();
+        // ---- conv3^T: da2[(iy,ix)][c] = sum_{tap,o} da3[(iy-ky, ix-kx)][o] w3[o][tap][c], times relu'(a2)
+        for (int rb = 0; rb < (P2 + 15) / 16; ++rb) {
+            int p = rb * 16 + l15;
+            int pp = p < P2 ? p : 0;
+            int iy = pp / W2, ix = pp - iy * W2;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                int ky = tap / 3, kx = tap - 3 * ky;
+                int oy = iy - ky, ox = ix - kx;
+                bool ok = oy >= 0 && oy < W3 && ox >= 0 && ox < W3;
+                const bf16_t* src = d3 + (ok ? oy * W3 + ox : P3) * A2_PITCH + g4 * 8;
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(src), wf3[2 * tap],
+                                                              acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(src + 32),
+                                                              wf3[2 * tap + 1], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int pix = rb * 16 + g4 * 4 + r;
+                if (pix < P2) {
+                    bf16_t* cell = a2m + pix * A2_PITCH + wave * 16 + l15;     // this wave's columns only
+                    *cell = (bf2f(*cell) > 0.f) ? f2bf(acc[r]) : (bf16_t)0;
+                }
+            }
+        }
+        __syncthreads();                    // a2m now holds da2
+        {
+            uint4* dst = reinterpret_cast<uint4*>(a.da2 + (long)img * P2 * 64);
+            for (int t = tid; t < P2 * 8; t += 256)
+                dst[t] = *reinterpret_cast<const uint4*>(a2m + (t >> 3) * A2_PITCH + (t & 7) * 8);
+        }
+        // ---- conv2^T for this wave's parity class: input pixel (2 iy2 + py, 2 ix2 + px), taps (py + 2a, px + 2b)
+        for (int rb = 0; rb < (100 + 15) / 16; ++rb) {
+            int q = rb * 16 + l15;
+            int qq = q < 100 ? q : 0;
+            int iy2 = qq / 10, ix2 = qq - iy2 * 10;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int oy = iy2 - (t >> 1), ox = ix2 - (t & 1);
+                bool ok = oy >= 0 && oy < W2 && ox >= 0 && ox < W2;
+                const bf16_t* src = a2m + (ok ? oy * W2 + ox : P2) * A2_PITCH + g4 * 8;
+                bf16x8 lo = *reinterpret_cast<const bf16x8*>(src), hi = *reinterpret_cast<const bf16x8*>(src + 32);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, wf2[2 * t][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, wf2[2 * t][1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wf2[2 * t + 1][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, wf2[2 * t + 1][1], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int qr = rb * 16 + g4 * 4 + r;
+                if (qr < 100) {
+                    int y2 = qr / 10, x2 = qr - y2 * 10;
+                    bf16_t* cell = a1m + ((2 * y2 + py) * W1 + 2 * x2 + px) * A1_PITCH + l15;  // this class's pixels only
+                    cell[0] = (bf2f(cell[0]) > 0.f) ? f2bf(acc0[r]) : (bf16_t)0;
+                    cell[16] = (bf2f(cell[16]) > 0.f) ? f2bf(acc1[r]) : (bf16_t)0;
+                }
+            }
+        }
+        __syncthreads();                    // a1m now holds da1
+        {
+            uint4* dst = reinterpret_cast<uint4*>(a.da1 + (long)img * P1 * 32);
+            for (int t = tid; t < P1 * 4; t += 256)
+                dst[t] = *reinterpret_cast<const uint4*>(a1m + (t >> 2) * A1_PITCH + (t & 3) * 8);
+        }
+    }
+}
+
 }  // namespace
 
 // Does the specialised path cover this conv?  (Nature conv1 on 4-frame stacks)
@@ -469,4 +609,25 @@ PDA_EXPORT void pda_cnn_fwd_stack(const void* const* frames, const void* const* 
     }
     int blocks = batch < 256 ? batch : 256;         // one workgroup per CU (88 KB LDS), looping over images
     hipLaunchKernelGGL(cnn_fwd_stack_kernel, dim3(blocks, ngroups), dim3(256), lds, stream, a);
+}
+
+// conv3^T -> relu'(a2) -> conv2^T -> relu'(a1): the data gradients da2 [(b, 9x9)][64] and da1 [(b, 20x20)][32]
+// of the Nature CNN from da3 [(b, 7x7)][64] in one launch (cnn_dgrad_stack_kernel).  84x84 inputs only.
+PDA_EXPORT int pda_cnn_dgrad_stack_supported(int H, int W, int C) { return (H == 84 && W == 84 && C == 4) ? 1 : 0; }
+
+PDA_EXPORT void pda_cnn_dgrad_stack(const void* da3, const void* a2, const void* a1, const void* w3, const void* w2,
+                                    void* da2, void* da1, int batch, hipStream_t stream) {
+    DgradStackArgs a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3,
+                        (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch};
+    size_t work = ((size_t)400 * A1_PITCH + (size_t)82 * A2_PITCH + (size_t)50 * A2_PITCH) * 2;
+    size_t lds = 9 * 4096 * 2;          // the weight staging tiles are the larger tenant
+    if (work > lds) lds = work;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    int blocks = batch < 512 ? batch : 512;
+    hipLaunchKernelGGL(cnn_dgrad_stack_kernel, dim3(blocks), dim3(256), lds, stream, a);
 }

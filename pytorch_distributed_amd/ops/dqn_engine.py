@@ -215,13 +215,14 @@ class _Acts(object):
             self.da3 = z(B * g.P3, 64)
             self.da2 = z(B * g.H2 * g.W2, 64)
             self.da1 = z(B * g.H1 * g.W1, 32)
+            self.stack_dgrad = nn.cnn_dgrad_stack_supported(g.H, g.W, g.C)
             # gather-form data gradients need no dcol matrices; odd layer geometries fall back to
             # dcol GEMM + col2im
             # (measured on MI355X: the gather form is ~4 % slower end to end at batch 128 and 4096 --
             # 4-9 latency-bound k-tiles against one output-bound tile + a bandwidth pass -- so it is
             # opt-in; it saves the dcol buffers: 0.9 GB at batch 4096)
             self.fused_dgrad = g.H1 % 2 == 0 and g.W1 % 2 == 0 and os.environ.get("PDA_FUSED_DGRAD", "0") == "1"
-            if not self.fused_dgrad:
+            if not self.fused_dgrad and not self.stack_dgrad:
                 self.dcol3 = z(B * g.P3, g.K3)
                 self.dcol2 = z(B * g.H2 * g.W2, g.K2)
 
@@ -430,6 +431,28 @@ class DqnCnnEngine(object):
                 fn()
 
         nn.linear_dgrad(a.dh1, on.w[3], a.a3[0], a.da3, B, g.HID, g.F, g.HID, g.F, g.F, g.F, act=nn.ACT_RELU)
+        if a.stack_dgrad:
+            # both conv data gradients in one launch (per-image, LDS-resident), then the two weight gradients
+            nn.cnn_dgrad_stack(a.da3, a.a2[0], a.a1[0], on.w[2], on.w[1], a.da2, a.da1, B)
+            nn.conv_wgrad(a.da3, a.a2[0], w3s, b3s, B, g.H2, g.W2, 64, 3, 3, 1, 64, ksplit=ks3, slice_stride=st3,
+                          bslice_stride=bst3)
+            nn.conv_wgrad(a.da2, a.a1[0], w2s, b2s, B, g.H1, g.W1, 32, 4, 4, 2, 64, ksplit=ks2, slice_stride=st2,
+                          bslice_stride=bst2)
+        else:
+            self._backward_conv_layerwise(a, on, B, M3, M2, on_side, (w3s, b3s, ks3, st3, bst3),
+                                          (w2s, b2s, ks2, st2, bst2))
+        nn.conv_wgrad_u8(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / self.norm_val,
+                         ksplit=ks1, slice_stride=st1, bslice_stride=bst1)
+        if fork:                # join: everything queued on the side stream (incl. fc wgrads put there by the caller)
+            self.ev_side.record(side)
+            cur.wait_event(self.ev_side)
+        if reduce:
+            self.reduce.run()
+
+    def _backward_conv_layerwise(self, a, on, B, M3, M2, on_side, s3, s2):
+        """conv3 / conv2 weight and data gradients as separate launches (generic geometries; PDA_FUSED_BWD=0)."""
+        g = self.geom
+        (w3s, b3s, ks3, st3, bst3), (w2s, b2s, ks2, st2, bst2) = s3, s2
         on_side(self.ev_da3, lambda: nn.conv_wgrad(a.da3, a.a2[0], w3s, b3s, B, g.H2, g.W2, 64, 3, 3, 1, 64,
                                                    ksplit=ks3, slice_stride=st3, bslice_stride=bst3))
         if a.fused_dgrad:
@@ -444,13 +467,6 @@ class DqnCnnEngine(object):
         else:
             nn.linear_dgrad(a.da2, on.w[1], None, a.dcol2, M2, 64, g.K2, 64, g.K2, 0, g.K2)
             nn.col2im(a.dcol2, a.a1[0], a.da1, B, g.H1, g.W1, 32, 4, 4, 2, act=nn.ACT_RELU)
-        nn.conv_wgrad_u8(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / self.norm_val,
-                         ksplit=ks1, slice_stride=st1, bslice_stride=bst1)
-        if fork:                # join: everything queued on the side stream (incl. fc wgrads put there by the caller)
-            self.ev_side.record(side)
-            cur.wait_event(self.ev_side)
-        if reduce:
-            self.reduce.run()
 
     def grads_torch_layout(self):
         """The flat gradient re-ordered to PyTorch's parameter layout (tests, debugging)."""

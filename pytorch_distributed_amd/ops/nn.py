@@ -65,6 +65,10 @@ def _L():
         L.pda_cnn_fwd_stack_supported.restype = c_int
         L.pda_cnn_fwd_stack.argtypes = [_vp] * 11 + [c_int] * 5 + [c_float, _vp]
         L.pda_cnn_fwd_stack.restype = None
+        L.pda_cnn_dgrad_stack_supported.argtypes = [c_int] * 3
+        L.pda_cnn_dgrad_stack_supported.restype = c_int
+        L.pda_cnn_dgrad_stack.argtypes = [_vp] * 7 + [c_int, _vp]
+        L.pda_cnn_dgrad_stack.restype = None
         L.pda_linear_wgrad2.argtypes = [_vp] * 4 + [c_int] + [_vp] * 5 + [_vp]
         L.pda_linear_wgrad2.restype = None
         L.pda_conv_dgrad.argtypes = [_vp] * 4 + [c_int] * 9 + [_vp]
@@ -100,6 +104,18 @@ def cnn_fwd_stack(frames, idx, w1, b1, w2, b2, w3, b3, a1, a2, a3, batch, H, W, 
     n = len(frames)
     _L().pda_cnn_fwd_stack(_arr(frames), _arr(idx), _arr(w1), _arr(b1), _arr(w2), _arr(b2), _arr(w3), _arr(b3),
                            _arr(a1), _arr(a2), _arr(a3), n, batch, H, W, C, float(scale), _stream())
+
+
+def cnn_dgrad_stack_supported(H, W, C):
+    import os
+    return os.environ.get("PDA_FUSED_BWD", "1") != "0" and bool(_L().pda_cnn_dgrad_stack_supported(H, W, C))
+
+
+def cnn_dgrad_stack(da3, a2, a1, w3, w2, da2, da1, batch):
+    """da2 = conv3^T(da3) * relu'(a2), da1 = conv2^T(da2) * relu'(a1) for the Nature CNN on 84x84 inputs, one
+    workgroup per image with every intermediate in LDS (no dcol matrices, no col2im passes)."""
+    _L().pda_cnn_dgrad_stack(_ptr(da3), _ptr(a2), _ptr(a1), _ptr(w3), _ptr(w2), _ptr(da2), _ptr(da1), batch,
+                             _stream())
 
 
 def conv1_wgrad_slices(batch):

@@ -232,3 +232,31 @@ def test_cnn_fwd_stack_matches_layerwise(nn, batch, groups):
         if outs[gi][0] is not None:
             close(nn.from_nhwc(outs[gi][0], batch, 20, 20, 32), r1)
             close(nn.from_nhwc(outs[gi][1], batch, 9, 9, 64), r2, 3e-2, 3e-2)
+
+
+@pytest.mark.parametrize("batch", [3, 128, 600])
+def test_cnn_dgrad_stack_matches_torch(nn, batch):
+    """da3 -> conv3^T, relu'(a2) -> da2 -> conv2^T, relu'(a1) -> da1 in ONE launch == torch autograd."""
+    if not nn.cnn_dgrad_stack_supported(84, 84, 4):
+        pytest.skip("fused backward not available")
+    torch.manual_seed(11)
+    a1 = bf(torch.relu(torch.randn(batch, 32, 20, 20, device="cuda"))).requires_grad_(True)
+    w2 = bf(torch.randn(64, 32, 4, 4, device="cuda") / 22)
+    w3 = bf(torch.randn(64, 64, 3, 3, device="cuda") / 24)
+    z2 = F.conv2d(a1, w2, None, stride=2) + 0.1
+    a2 = torch.relu(z2)
+    a2b = bf(a2.detach())
+    da3 = bf(torch.randn(batch, 64, 7, 7, device="cuda"))
+    # reference with the same bf16 rounding of the intermediate gradient
+    a2_leaf = a2b.clone().requires_grad_(True)
+    F.conv2d(a2_leaf, w3, None, stride=1).backward(da3)
+    da2_ref = bf(a2_leaf.grad * (a2b > 0))
+    a1_leaf = a1.detach().clone().requires_grad_(True)
+    F.conv2d(a1_leaf, w2, None, stride=2).backward(da2_ref)
+    da1_ref = a1_leaf.grad * (a1.detach() > 0)
+    da2 = torch.full((batch * 81, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    da1 = torch.full((batch * 400, 32), 7.0, dtype=torch.bfloat16, device="cuda")
+    nn.cnn_dgrad_stack(nn.nhwc(da3), nn.nhwc(a2b), nn.nhwc(a1.detach()), nn.pack_conv_weight(w3),
+                       nn.pack_conv_weight(w2), da2, da1, batch)
+    close(nn.from_nhwc(da2, batch, 9, 9, 64), da2_ref, 3e-2, 3e-2)
+    close(nn.from_nhwc(da1, batch, 20, 20, 32), da1_ref, 3e-2, 3e-2)
