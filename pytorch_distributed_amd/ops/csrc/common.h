@@ -18,8 +18,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 __device__ __forceinline__ float bf2f(bf16_t b) {
     return __builtin_bit_cast(float, ((uint32_t)b) << 16);
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {   // one v_cvt_pk_bf16_f32
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    f32x2_ v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
 }
 // 4 uint8 (one dword) -> 4 bf16 bit patterns; exact (0..255 fits 8 mantissa bits)
 __device__ __forceinline__ uint2 u8x4_to_bf16x4(uint32_t w) {

@@ -48,7 +48,9 @@ __device__ __forceinline__ void patch_issue(PatchRegs& r, const uint8_t* frames,
         r.v[i] = src[t < n16 ? t : 0];      // unconditional: lanes past the end re-read element 0
     }
 }
-template <int IT = PATCH_IT>
+// PLANE_CHUNKS / PLANE_PAD: 16-element chunks per channel plane and bf16 elements of padding after each plane
+// (0 / 0 = contiguous image).
+template <int IT = PATCH_IT, int PLANE_CHUNKS = 0, int PLANE_PAD = 0>
 __device__ __forceinline__ void patch_commit(const PatchRegs& r, long frame_bytes, bf16_t* patch, int tid) {
     int n16 = (int)(frame_bytes >> 4);
 #pragma unroll
@@ -57,7 +59,9 @@ __device__ __forceinline__ void patch_commit(const PatchRegs& r, long frame_byte
         if (t < n16) {
             uint4 lo, hi;
             u8x16_to_bf16(r.v[i], lo, hi);
-            uint4* dst = reinterpret_cast<uint4*>(patch + (long)t * 16);
+            int pad = 0;
+            if constexpr (PLANE_PAD != 0) pad = (t / PLANE_CHUNKS) * PLANE_PAD;
+            uint4* dst = reinterpret_cast<uint4*>(patch + (long)t * 16 + pad);
             dst[0] = lo;
             dst[1] = hi;
         }
@@ -281,48 +285,84 @@ struct FwdStackArgs {
 
 #define A1_PITCH 40     // bf16 elements per a1 pixel row in LDS (32 channels + 8 pad = 5 slots)
 #define A2_PITCH 72     // 64 channels + 8 pad = 9 slots
+#define FWD_PLANE 7104  // bf16 elements per channel plane of the forward kernel's frame patch: 84 * 84 + 48, == 32 (mod 64) dwords
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void pin_agpr(bf16x8& v) { asm volatile("" : "+a"(v)); }
 // phase stamp: 16 slots per image, first 4 images of the stamped workgroup
 #define STACK_STAMP(prof, it, slot)                                                          \
     if ((prof) && (it) < 4 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)        \
         (prof)[(it) * 16 + (slot)] = (long long)__builtin_readcyclecounter();
 
+// LDS pitches of the forward kernel's activations (bf16 elements), chosen with tools/probes/lds_conflicts.py
+// so that the A-fragment gathers of conv2 (stride-2 pixels of a1) and conv3 (pixels of a2) are served in
+// 4.7 and 5.0 LDS cycles per ds_read_b128 (4 = conflict-free; the dense pitches 40 / 72 gave 8 and 10).
+#define F1_CP 40        // a1: per pixel (32 channels + 8 pad)
+#define F1_RP 808       // a1: per row of 20 pixels (+ 8 pad)
+#define F2_CP 80        // a2: per pixel (64 channels + 16 pad)
+#define F2_RP 816       // a2: per row of 9 pixels (+ 96 pad)
+
+// one k-step of the swapped product: D[channel][pixel] += W[channel][k] * X[k][pixel].  With the weights as
+// the A operand a lane ends up with 4 CONSECUTIVE channels (4 g4 .. + 3) of ONE pixel (l15), which leave as
+// one packed 8-byte store instead of four 2-byte ones.
+__device__ __forceinline__ f32x4 mfma_wx(bf16x8 w, bf16x8 x, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc, 0, 0, 0);
+}
+__device__ __forceinline__ uint2 relu_pack4(f32x4 v, float s, f32x4 bias) {
+    return make_uint2(pack2bf(fmaxf(v[0] * s + bias[0], 0.f), fmaxf(v[1] * s + bias[1], 0.f)),
+                      pack2bf(fmaxf(v[2] * s + bias[2], 0.f), fmaxf(v[3] * s + bias[3], 0.f)));
+}
+// scheduling pattern of one row block: per MFMA one LDS read (next block's fragment) and a few VALU
+// instructions (previous block's epilogue) ride in its shadow
+#define STACK_SCHED(n_mfma, per_mfma_reads_num, per_mfma_reads_den, valu)                        \
+    _Pragma("unroll") for (int q_ = 0; q_ < (n_mfma) / (per_mfma_reads_den); ++q_) {           \
+        __builtin_amdgcn_sched_group_barrier(0x008, (per_mfma_reads_den), 0);                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, (per_mfma_reads_num), 0);                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, (valu), 0);                                  \
+    }
+
 __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     constexpr int C = 4, H = 84, W = 84, KS1 = 8, KS2 = 16, KS3 = 18;
     constexpr int OW1 = 20, P1 = 400, OW2 = 9, P2 = 81, OW3 = 7, P3 = 49;
+    constexpr int NRB2 = (P2 + 15) / 16, NRB3 = (P3 + 15) / 16;
     constexpr long frame_bytes = (long)C * H * W;
+    constexpr int PLANE = FWD_PLANE;        // channel-plane pitch of the patch
     const int grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, l15 = lane & 15;
     bf16_t* patch = lds;
-    bf16_t* a1s = lds + frame_bytes;
+    bf16_t* a1s = lds + C * PLANE;
     bf16_t* a2s = lds;                      // reuses the patch region once conv1 is done
 
     PatchRegs pr;                           // frame loads go out first: the weights arrive behind them
     if ((int)blockIdx.x < a.batch) patch_issue<7>(pr, a.frames[grp], a.idx[grp], frame_bytes, blockIdx.x, tid);
-    // weights -> B fragments (lane: n = l15 + 16 nb, k = 32 ks + 8 g4 .. +7)
+    // weight fragments (lane: channel n = l15 + 16 nb, 8 consecutive k).  conv1's k-steps are regrouped as
+    // (ky = ks, c = g4, kx 0..7) -- any order works as long as both operands agree -- see conv1 below.
     bf16x8 wf1[KS1][2], wf2[KS2], wf3[KS3];
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
-            wf1[ks][nb] = *reinterpret_cast<const bf16x8*>(a.w1[grp] + (long)(nb * 16 + l15) * 256 + ks * 32 + g4 * 8);
+            wf1[ks][nb] = *reinterpret_cast<const bf16x8*>(a.w1[grp] + (long)(nb * 16 + l15) * 256 + g4 * 64 + ks * 8);
 #pragma unroll
     for (int ks = 0; ks < KS2; ++ks)
         wf2[ks] = *reinterpret_cast<const bf16x8*>(a.w2[grp] + (long)(wave * 16 + l15) * 512 + ks * 32 + g4 * 8);
 #pragma unroll
     for (int ks = 0; ks < KS3; ++ks)
         wf3[ks] = *reinterpret_cast<const bf16x8*>(a.w3[grp] + (long)(wave * 16 + l15) * 576 + ks * 32 + g4 * 8);
-    const float b10 = a.b1[grp][l15], b11 = a.b1[grp][16 + l15];
-    const float b2v = a.b2[grp][wave * 16 + l15], b3v = a.b3[grp][wave * 16 + l15];
+    // biases of the 4 channels a lane owns in the swapped product
+    const f32x4 b10 = *reinterpret_cast<const f32x4*>(a.b1[grp] + 4 * g4);
+    const f32x4 b11 = *reinterpret_cast<const f32x4*>(a.b1[grp] + 16 + 4 * g4);
+    const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2[grp] + wave * 16 + 4 * g4);
+    const f32x4 b3v = *reinterpret_cast<const f32x4*>(a.b3[grp] + wave * 16 + 4 * g4);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     bool pinned = false;
     int it_no = 0;
 
     for (int img = blockIdx.x; img < a.batch; img += gridDim.x, ++it_no) {
         STACK_STAMP(a.prof, it_no, 0)
         __syncthreads();                    // previous image fully consumed (a2s aliases the patch)
-        patch_commit<7>(pr, frame_bytes, patch, tid);
+        patch_commit<7, H * W / 16, PLANE - H * W>(pr, frame_bytes, patch, tid);
         __syncthreads();
         STACK_STAMP(a.prof, it_no, 1)
         if (img + (int)gridDim.x < a.batch)
@@ -331,41 +371,58 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
         for (int ks = 0; ks < KS1; ++ks) { pin_agpr(wf1[ks][0]); pin_agpr(wf1[ks][1]); }
 
         // ---- conv1: 8x8 s4, 32 channels -> a1s (25 row blocks of 16 pixels, exactly; wave w takes w, w + 4, ..)
-        // The A-fragments of row block i + 1 are in flight while row block i is multiplied (two register
-        // sets, loop fully unrolled); the scheduling barriers keep the compiler from re-serialising them.
+        // Pixel fragment of lane (pixel l15, g4): channel g4, kernel row ks, kx 0..7 = 16 bytes at an 8-byte
+        // aligned address (one ds_read2_b64).  Pixel m sits at dword 2 m + 128 oy of its row set, so 16
+        // consecutive pixels cover 32 distinct banks whatever rows they span: conflict-free.
+        // Software pipeline over row blocks (fully unrolled): the fragments of block i + 1 are fetched and
+        // the outputs of block i - 1 are scaled / packed / stored in the shadow of block i's MFMAs.
         {
-            auto load1 = [&](bf16x8 (&af)[KS1], int rb) {
+            auto load1 = [&](bf16x8 (&xf)[KS1], int rb) {
                 int m = rb * 16 + l15;
                 int oy = m / OW1, ox = m - oy * OW1;
-                const bf16_t* base = patch + (4 * oy + g4) * W + 4 * ox;
+                const bf16_t* base = patch + g4 * PLANE + (4 * oy) * W + 4 * ox;
 #pragma unroll
-                for (int ks = 0; ks < KS1; ++ks)        // c = ks / 2, ky = (ks % 2) * 4 + g4
-                    af[ks] = patch_frag(base + (ks >> 1) * (H * W) + (ks & 1) * (4 * W));
+                for (int ks = 0; ks < KS1; ++ks) xf[ks] = patch_frag(base + ks * W);
             };
-            bf16x8 afa[KS1], afb[KS1];
-            load1(afa, wave);
+            auto mul1 = [&](const bf16x8 (&xf)[KS1], f32x4& c0, f32x4& c1) {
+                c0 = zero4; c1 = zero4;
 #pragma unroll
-            for (int it = 0; it < 7; ++it) {
-                const int rb = wave + 4 * it;
-                if (rb < P1 / 16) {                     // wave-uniform
-                    auto& cur = (it & 1) ? afb : afa;
-                    auto& nxt = (it & 1) ? afa : afb;
-                    if (rb + 4 < P1 / 16) load1(nxt, rb + 4);
-                    __builtin_amdgcn_sched_barrier(0);
-                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ks = 0; ks < KS1; ++ks) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[ks], wf1[ks][0], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[ks], wf1[ks][1], acc1, 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {       // D layout: col = lane & 15, row = (lane >> 4) * 4 + r
-                        int pix = rb * 16 + g4 * 4 + r;
-                        a1s[pix * A1_PITCH + l15] = f2bf(fmaxf(acc0[r] * a.scale + b10, 0.f));
-                        a1s[pix * A1_PITCH + 16 + l15] = f2bf(fmaxf(acc1[r] * a.scale + b11, 0.f));
-                    }
+                for (int ks = 0; ks < KS1; ++ks) {
+                    c0 = mfma_wx(wf1[ks][0], xf[ks], c0);
+                    c1 = mfma_wx(wf1[ks][1], xf[ks], c1);
                 }
+            };
+            auto store1 = [&](const f32x4& c0, const f32x4& c1, int rb) {
+                int pix = rb * 16 + l15;
+                int y = pix / OW1, x = pix - y * OW1;
+                bf16_t* dst = a1s + y * F1_RP + x * F1_CP + 4 * g4;
+                *reinterpret_cast<uint2*>(dst) = relu_pack4(c0, a.scale, b10);
+                *reinterpret_cast<uint2*>(dst + 16) = relu_pack4(c1, a.scale, b11);
+            };
+            bf16x8 xa[KS1], xb[KS1];
+            f32x4 ca0, ca1, cb0, cb1;
+            load1(xa, wave);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {            // row blocks wave + 4 it <= 23: every wave has them
+                const int rb = wave + 4 * it;
+                auto& cur = (it & 1) ? xb : xa;
+                auto& nxt = (it & 1) ? xa : xb;
+                if (it < 5) load1(nxt, rb + 4);
+                else if (wave == 0) load1(nxt, 24);     // the 25th block is wave 0's
+                if (it & 1) mul1(cur, cb0, cb1); else mul1(cur, ca0, ca1);
+                if (it > 0) { if (it & 1) store1(ca0, ca1, rb - 4); else store1(cb0, cb1, rb - 4); }
+                STACK_SCHED(2 * KS1, 1, 2, 4)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (wave == 0) {
+                mul1(xa, ca0, ca1);                     // it = 6
+                store1(cb0, cb1, 20);
+                STACK_SCHED(2 * KS1, 0, 2, 4)
+                __builtin_amdgcn_sched_barrier(0);
+                store1(ca0, ca1, 24);
+            } else {
+                store1(cb0, cb1, wave + 20);
             }
         }
         STACK_STAMP(a.prof, it_no, 2)
@@ -373,8 +430,16 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
         STACK_STAMP(a.prof, it_no, 3)
         if (a.a1[grp]) {                    // coalesced copy-out for the backward pass (4 x 16 B per pixel)
             uint4* dst = reinterpret_cast<uint4*>(a.a1[grp] + (long)img * P1 * 32);
-            for (int t = tid; t < P1 * 4; t += 256)
-                dst[t] = *reinterpret_cast<const uint4*>(a1s + (t >> 2) * A1_PITCH + (t & 3) * 8);
+            auto a1_chunk = [&](int t) {
+                int pix = t >> 2;
+                int y = pix / OW1, x = pix - y * OW1;
+                return *reinterpret_cast<const uint4*>(a1s + y * F1_RP + x * F1_CP + (t & 3) * 8);
+            };
+            uint4 v0 = a1_chunk(tid), v1 = a1_chunk(tid + 256), v2 = a1_chunk(tid + 512), v3 = a1_chunk(tid + 768),
+                  v4 = a1_chunk(tid + 1024), v5 = a1_chunk(tid + 1280);
+            dst[tid] = v0; dst[tid + 256] = v1; dst[tid + 512] = v2; dst[tid + 768] = v3;
+            dst[tid + 1024] = v4; dst[tid + 1280] = v5;
+            if (tid < P1 * 4 - 1536) dst[tid + 1536] = a1_chunk(tid + 1536);
         }
         STACK_STAMP(a.prof, it_no, 4)
         if (!pinned) {
@@ -387,81 +452,104 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
         STACK_STAMP(a.prof, it_no, 5)
         // ---- conv2: 4x4 s2, 32 -> 64; wave w computes output channels [16 w, 16 w + 16) -> a2s
         {
-            auto load2 = [&](bf16x8 (&af)[KS2], int rb) {
+            auto load2 = [&](bf16x8 (&xf)[KS2], int rb) {
                 int m = rb * 16 + l15;
                 int mm = m < P2 ? m : 0;
                 int oy = mm / OW2, ox = mm - oy * OW2;
-                const bf16_t* base = a1s + ((2 * oy) * OW1 + 2 * ox) * A1_PITCH + g4 * 8;
+                const bf16_t* base = a1s + (2 * oy) * F1_RP + (2 * ox) * F1_CP + g4 * 8;
 #pragma unroll
                 for (int ks = 0; ks < KS2; ++ks)        // one tap (ky, kx) = 32 channels per k-step
-                    af[ks] = *reinterpret_cast<const bf16x8*>(base + ((ks >> 2) * OW1 + (ks & 3)) * A1_PITCH);
+                    xf[ks] = *reinterpret_cast<const bf16x8*>(base + (ks >> 2) * F1_RP + (ks & 3) * F1_CP);
             };
-            bf16x8 afa[KS2], afb[KS2];
-            load2(afa, 0);
-#pragma unroll
-            for (int rb = 0; rb < (P2 + 15) / 16; ++rb) {
-                auto& cur = (rb & 1) ? afb : afa;
-                auto& nxt = (rb & 1) ? afa : afb;
-                if (rb + 1 < (P2 + 15) / 16) load2(nxt, rb + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            auto mul2 = [&](const bf16x8 (&xf)[KS2], f32x4& c0, f32x4& c1) {
+                c0 = zero4; c1 = zero4;
 #pragma unroll
                 for (int ks = 0; ks < KS2; ks += 2) {   // two independent accumulation chains
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[ks], wf2[ks], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[ks + 1], wf2[ks + 1], acc1, 0, 0, 0);
+                    c0 = mfma_wx(wf2[ks], xf[ks], c0);
+                    c1 = mfma_wx(wf2[ks + 1], xf[ks + 1], c1);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto store2 = [&](const f32x4& c0, const f32x4& c1, int rb) {
+                int pix = rb * 16 + l15;
+                if (pix < P2) {
+                    int y = pix / OW2, x = pix - y * OW2;
+                    *reinterpret_cast<uint2*>(a2s + y * F2_RP + x * F2_CP + wave * 16 + 4 * g4) =
+                        relu_pack4(c0 + c1, 1.f, b2v);
+                }
+            };
+            bf16x8 xa[KS2], xb[KS2];
+            f32x4 ca0, ca1, cb0, cb1;
+            load2(xa, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int pix = rb * 16 + g4 * 4 + r;
-                    if (pix < P2) a2s[pix * A2_PITCH + wave * 16 + l15] = f2bf(fmaxf(acc0[r] + acc1[r] + b2v, 0.f));
-                }
+            for (int rb = 0; rb < NRB2; ++rb) {
+                auto& cur = (rb & 1) ? xb : xa;
+                auto& nxt = (rb & 1) ? xa : xb;
+                if (rb + 1 < NRB2) load2(nxt, rb + 1);
+                if (rb & 1) mul2(cur, cb0, cb1); else mul2(cur, ca0, ca1);
+                if (rb > 0) { if (rb & 1) store2(ca0, ca1, rb - 1); else store2(cb0, cb1, rb - 1); }
+                STACK_SCHED(KS2, 1, 1, 2)
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if ((NRB2 - 1) & 1) store2(cb0, cb1, NRB2 - 1); else store2(ca0, ca1, NRB2 - 1);
         }
         STACK_STAMP(a.prof, it_no, 6)
         __syncthreads();                    // a2 complete
         STACK_STAMP(a.prof, it_no, 7)
         if (a.a2[grp]) {
             uint4* dst = reinterpret_cast<uint4*>(a.a2[grp] + (long)img * P2 * 64);
-            for (int t = tid; t < P2 * 8; t += 256)
-                dst[t] = *reinterpret_cast<const uint4*>(a2s + (t >> 3) * A2_PITCH + (t & 7) * 8);
+            auto a2_chunk = [&](int t) {
+                int pix = t >> 3;
+                int y = pix / OW2, x = pix - y * OW2;
+                return *reinterpret_cast<const uint4*>(a2s + y * F2_RP + x * F2_CP + (t & 7) * 8);
+            };
+            uint4 v0 = a2_chunk(tid), v1 = a2_chunk(tid + 256);
+            dst[tid] = v0; dst[tid + 256] = v1;
+            if (tid < P2 * 8 - 512) dst[tid + 512] = a2_chunk(tid + 512);
         }
         STACK_STAMP(a.prof, it_no, 8)
         // ---- conv3: 3x3 s1, 64 -> 64 -> global a3 [(img, pix)][64]
         {
             bf16_t* out3 = a.a3[grp] + (long)img * P3 * 64;
-            auto load3 = [&](bf16x8 (&af)[KS3], int rb) {
+            auto load3 = [&](bf16x8 (&xf)[KS3], int rb) {
                 int m = rb * 16 + l15;
                 int mm = m < P3 ? m : 0;
                 int oy = mm / OW3, ox = mm - oy * OW3;
-                const bf16_t* base = a2s + (oy * OW2 + ox) * A2_PITCH + g4 * 8;
+                const bf16_t* base = a2s + oy * F2_RP + ox * F2_CP + g4 * 8;
 #pragma unroll
                 for (int ks = 0; ks < KS3; ++ks) {      // tap = ks / 2, channel half = ks % 2
                     int tap = ks >> 1, ky = tap / 3, kx = tap - 3 * ky;
-                    af[ks] = *reinterpret_cast<const bf16x8*>(base + (ky * OW2 + kx) * A2_PITCH + (ks & 1) * 32);
+                    xf[ks] = *reinterpret_cast<const bf16x8*>(base + ky * F2_RP + kx * F2_CP + (ks & 1) * 32);
                 }
             };
-            bf16x8 afa[KS3], afb[KS3];
-            load3(afa, 0);
-#pragma unroll
-            for (int rb = 0; rb < (P3 + 15) / 16; ++rb) {
-                auto& cur = (rb & 1) ? afb : afa;
-                auto& nxt = (rb & 1) ? afa : afb;
-                if (rb + 1 < (P3 + 15) / 16) load3(nxt, rb + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            auto mul3 = [&](const bf16x8 (&xf)[KS3], f32x4& c0, f32x4& c1) {
+                c0 = zero4; c1 = zero4;
 #pragma unroll
                 for (int ks = 0; ks < KS3; ks += 2) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[ks], wf3[ks], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[ks + 1], wf3[ks + 1], acc1, 0, 0, 0);
+                    c0 = mfma_wx(wf3[ks], xf[ks], c0);
+                    c1 = mfma_wx(wf3[ks + 1], xf[ks + 1], c1);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto store3 = [&](const f32x4& c0, const f32x4& c1, int rb) {
+                int pix = rb * 16 + l15;
+                if (pix < P3)
+                    *reinterpret_cast<uint2*>(out3 + (long)pix * 64 + wave * 16 + 4 * g4) = relu_pack4(c0 + c1, 1.f, b3v);
+            };
+            bf16x8 xa[KS3], xb[KS3];
+            f32x4 ca0, ca1, cb0, cb1;
+            load3(xa, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int pix = rb * 16 + g4 * 4 + r;
-                    if (pix < P3) out3[(long)pix * 64 + wave * 16 + l15] = f2bf(fmaxf(acc0[r] + acc1[r] + b3v, 0.f));
-                }
+            for (int rb = 0; rb < NRB3; ++rb) {
+                auto& cur = (rb & 1) ? xb : xa;
+                auto& nxt = (rb & 1) ? xa : xb;
+                if (rb + 1 < NRB3) load3(nxt, rb + 1);
+                if (rb & 1) mul3(cur, cb0, cb1); else mul3(cur, ca0, ca1);
+                if (rb > 0) { if (rb & 1) store3(ca0, ca1, rb - 1); else store3(cb0, cb1, rb - 1); }
+                STACK_SCHED(KS3, 1, 1, 2)
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if ((NRB3 - 1) & 1) store3(cb0, cb1, NRB3 - 1); else store3(ca0, ca1, NRB3 - 1);
         }
         STACK_STAMP(a.prof, it_no, 9)
     }
@@ -725,7 +813,7 @@ PDA_EXPORT void pda_cnn_fwd_stack(const void* const* frames, const void* const* 
         a.a1[i] = (bf16_t*)a1[i]; a.a2[i] = (bf16_t*)a2[i]; a.a3[i] = (bf16_t*)a3[i];
     }
     a.batch = batch; a.scale = scale; a.prof = g_stack_prof;
-    size_t lds = ((size_t)C * H * W + (size_t)400 * A1_PITCH) * 2;
+    size_t lds = ((size_t)4 * FWD_PLANE + (size_t)20 * F1_RP) * 2;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_fwd_stack_kernel),

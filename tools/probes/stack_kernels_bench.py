@@ -59,14 +59,16 @@ for B in (128, 1024):
     idx = torch.randint(0, 4096, (B,), dtype=torch.int32, device=dev)
     a1 = torch.zeros(B * 400, 32, dtype=bf, device=dev); a2 = torch.zeros(B * 81, 64, dtype=bf, device=dev)
     a3 = torch.zeros(B * 49, 64, dtype=bf, device=dev)
-    prof = torch.zeros(64, dtype=torch.int64, device=dev)
+    prof = torch.zeros(128, dtype=torch.int64, device=dev)
     for rep in range(2):
         L.pda_cnn_stack_prof(ctypes.c_void_p(prof.data_ptr()))
         nn.cnn_fwd_stack([mem, mem], [idx, idx], [w1] * 2, [b1] * 2, [w2] * 2, [b2] * 2, [w3] * 2, [b3] * 2,
                          [a1, None], [a2, None], [a3, a3], B, 84, 84, 4, 1 / 255.)
         torch.cuda.synchronize()
         L.pda_cnn_stack_prof(ctypes.c_void_p(0))
-    p = prof.cpu().view(4, 16)
+    fine = prof.cpu()[64:64 + 21]
+    print('conv1 fine stamps (image 1):', [int(v - fine[0]) for v in fine])
+    p = prof.cpu()[:64].view(4, 16)
     names = ["loop top", "committed", "conv1 done", "barrier", "a1 out", "pinned", "conv2 done", "barrier", "a2 out", "conv3 done"]
     for it in range(4):
         if p[it, 0] == 0:
