@@ -50,6 +50,27 @@ __device__ __forceinline__ void patch_issue(PatchRegs& r, const uint8_t* frames,
 }
 // PLANE_CHUNKS / PLANE_PAD: 16-element chunks per channel plane and bf16 elements of padding after each plane
 // (0 / 0 = contiguous image).
+// The replay index of an image is itself a global load: fetched inside patch_issue it puts a full memory
+// round trip (vmcnt(0)) in front of the frame loads of EVERY image.  Loops over images fetch the index one
+// image further ahead (frame_index) and issue from the resolved pointer.
+// The image number is made opaque so that the index stays a per-lane VGPR load with a counted wait at its
+// use; recognised as wave-uniform it is moved to an SGPR on the spot, behind a vmcnt(0) that also drains the
+// frame loads just issued.
+__device__ __forceinline__ long frame_index(const int* idx, int img, int batch) {
+    int iv = img < batch ? img : 0;
+    asm volatile("" : "+v"(iv));
+    return idx ? (long)idx[iv] : (long)iv;
+}
+template <int IT = PATCH_IT>
+__device__ __forceinline__ void patch_issue_at(PatchRegs& r, const uint8_t* frame, long frame_bytes, int tid) {
+    const uint4* src = reinterpret_cast<const uint4*>(frame);
+    int n16 = (int)(frame_bytes >> 4);
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        int t = tid + i * 256;
+        r.v[i] = src[t < n16 ? t : 0];
+    }
+}
 template <int IT = PATCH_IT, int PLANE_CHUNKS = 0, int PLANE_PAD = 0>
 __device__ __forceinline__ void patch_commit(const PatchRegs& r, long frame_bytes, bf16_t* patch, int tid) {
     int n16 = (int)(frame_bytes >> 4);
@@ -105,13 +126,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1FwdArgs a) {
     PatchRegs pr;
     const int part = blockIdx.x % a.parts, img0 = blockIdx.x / a.parts, img_step = gridDim.x / a.parts;
     const int rb_beg = part * nrb / a.parts, rb_end = (part + 1) * nrb / a.parts;
-    if (img0 < a.batch) patch_issue(pr, a.frames[grp], a.idx[grp], frame_bytes, img0, tid);
+    long f_nxt = frame_index(a.idx[grp], img0 + img_step, a.batch);
+    if (img0 < a.batch)
+        patch_issue_at(pr, a.frames[grp] + frame_index(a.idx[grp], img0, a.batch) * frame_bytes, frame_bytes, tid);
     for (int img = img0; img < a.batch; img += img_step) {
         __syncthreads();                // everyone is done reading the previous patch
         patch_commit(pr, frame_bytes, patch, tid);
         __syncthreads();
         if (img + img_step < a.batch)           // next image's loads fly under this image's MFMAs
-            patch_issue(pr, a.frames[grp], a.idx[grp], frame_bytes, img + img_step, tid);
+            patch_issue_at(pr, a.frames[grp] + f_nxt * frame_bytes, frame_bytes, tid);
+        f_nxt = frame_index(a.idx[grp], img + 2 * img_step, a.batch);
         bf16_t* out = a.out[grp] + (long)img * P * 32;
         for (int rb = rb_beg + wave; rb < rb_end; rb += 4) {
             int m = rb * 16 + l15;
@@ -184,8 +208,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
     };
     const int part = blockIdx.x % a.parts, img0 = blockIdx.x / a.parts, img_step = gridDim.x / a.parts;
     const int ch_beg = part * nchunk / a.parts, ch_end = (part + 1) * nchunk / a.parts;
+    long f_nxt = frame_index(a.idx, img0 + img_step, a.batch);
     if (img0 < a.batch) {
-        patch_issue(pr, a.frames, a.idx, frame_bytes, img0, tid);
+        patch_issue_at(pr, a.frames + frame_index(a.idx, img0, a.batch) * frame_bytes, frame_bytes, tid);
         dy_issue(img0);
     }
     for (int img = img0; img < a.batch; img += img_step) {
@@ -202,9 +227,10 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
             }
         }
         if (img + img_step < a.batch) {         // next image's loads fly under this image's MFMAs
-            patch_issue(pr, a.frames, a.idx, frame_bytes, img + img_step, tid);
+            patch_issue_at(pr, a.frames + f_nxt * frame_bytes, frame_bytes, tid);
             dy_issue(img + img_step);
         }
+        f_nxt = frame_index(a.idx, img + 2 * img_step, a.batch);
         for (int ch = ch_beg; ch < ch_end; ++ch) {
             __syncthreads();            // patch / dyt ready (first chunk); previous chunk's col consumed
             // expand im2col rows of pixels [32 ch, 32 ch + 32): item = (px, j = (c, ky)) -> 8 bf16 (kx 0..7)
@@ -288,6 +314,9 @@ struct FwdStackArgs {
 #define FWD_PLANE 7104  // bf16 elements per channel plane of the forward kernel's frame patch: 84 * 84 + 48, == 32 (mod 64) dwords
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// volatile LDS pointer: keeps two adjacent 8-byte reads as two ds_read_b64 (2 LDS cycles each, 64-bank rules);
+// merged into one ds_read2_b64 they cost 8 cycles under 32-bank rules
+typedef const volatile __attribute__((address_space(3))) u32x2* lds_v2;
 __device__ __forceinline__ void pin_agpr(bf16x8& v) { asm volatile("" : "+a"(v)); }
 // phase stamp: 16 slots per image, first 4 images of the stamped workgroup
 #define STACK_STAMP(prof, it, slot)                                                          \
@@ -321,6 +350,9 @@ __device__ __forceinline__ uint2 relu_pack4(f32x4 v, float s, f32x4 bias) {
         __builtin_amdgcn_sched_group_barrier(0x002, (valu), 0);                                  \
     }
 
+// MULTI: workgroups loop over several images (next frame prefetched under the current one); otherwise one
+// image per workgroup and no prefetch code at all.
+template <bool MULTI>
 __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     constexpr int C = 4, H = 84, W = 84, KS1 = 8, KS2 = 16, KS3 = 18;
@@ -335,7 +367,12 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
     bf16_t* a2s = lds;                      // reuses the patch region once conv1 is done
 
     PatchRegs pr;                           // frame loads go out first: the weights arrive behind them
-    if ((int)blockIdx.x < a.batch) patch_issue<7>(pr, a.frames[grp], a.idx[grp], frame_bytes, blockIdx.x, tid);
+    const int G = gridDim.x;
+    long f_nxt = MULTI ? frame_index(a.idx[grp], blockIdx.x + G, a.batch) : 0;
+    if ((int)blockIdx.x < a.batch) {       // first image: the index is needed at once, as a scalar
+        const long f0 = a.idx[grp] ? (long)a.idx[grp][blockIdx.x] : (long)blockIdx.x;
+        patch_issue_at<7>(pr, a.frames[grp] + f0 * frame_bytes, frame_bytes, tid);
+    }
     // weight fragments (lane: channel n = l15 + 16 nb, 8 consecutive k).  conv1's k-steps are regrouped as
     // (ky = ks, c = g4, kx 0..7) -- any order works as long as both operands agree -- see conv1 below.
     bf16x8 wf1[KS1][2], wf2[KS2], wf3[KS3];
@@ -356,33 +393,82 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
     const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2[grp] + wave * 16 + 4 * g4);
     const f32x4 b3v = *reinterpret_cast<const f32x4*>(a.b3[grp] + wave * 16 + 4 * g4);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    bool pinned = false;
     int it_no = 0;
+    // Per-lane LDS offsets (bf16 elements) of every fragment gather, output store and copy-out chunk, computed
+    // here -- in the shadow of the first frame / weight loads -- and made opaque so that the divisions are not
+    // re-materialised inside the phases (a workgroup with a single image has no loop to hoist them out of).
+    int ld1[7], st1[7], co1[7], ld2[NRB2], st2[NRB2], co2[3], ld3[NRB3], st3[NRB3];
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+        int m = (wave + 4 * it) * 16 + l15;         // it = 6 exists for wave 0 only
+        m = m < P1 ? m : 0;
+        int oy = m / OW1, ox = m - oy * OW1;
+        ld1[it] = g4 * PLANE + (4 * oy) * W + 4 * ox;
+        st1[it] = C * PLANE + oy * F1_RP + ox * F1_CP + 4 * g4;
+        int t = tid + it * 256, pix = (t < P1 * 4 ? t : 0) >> 2;
+        int y = pix / OW1, x = pix - y * OW1;
+        co1[it] = C * PLANE + y * F1_RP + x * F1_CP + (t & 3) * 8;
+        asm volatile("" : "+v"(ld1[it]), "+v"(st1[it]), "+v"(co1[it]));
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB2; ++rb) {
+        int m = rb * 16 + l15;
+        int mm = m < P2 ? m : 0;
+        int oy = mm / OW2, ox = mm - oy * OW2;
+        ld2[rb] = C * PLANE + (2 * oy) * F1_RP + (2 * ox) * F1_CP + g4 * 8;
+        st2[rb] = oy * F2_RP + ox * F2_CP + wave * 16 + 4 * g4;
+        asm volatile("" : "+v"(ld2[rb]), "+v"(st2[rb]));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int t = tid + i * 256, pix = (t < P2 * 8 ? t : 0) >> 3;
+        int y = pix / OW2, x = pix - y * OW2;
+        co2[i] = y * F2_RP + x * F2_CP + (t & 7) * 8;
+        asm volatile("" : "+v"(co2[i]));
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB3; ++rb) {
+        int m = rb * 16 + l15;
+        int mm = m < P3 ? m : 0;
+        int oy = mm / OW3, ox = mm - oy * OW3;
+        ld3[rb] = oy * F2_RP + ox * F2_CP + g4 * 8;
+        st3[rb] = m * 64 + wave * 16 + 4 * g4;        // global a3 offset within the image
+        asm volatile("" : "+v"(ld3[rb]), "+v"(st3[rb]));
+    }
 
-    for (int img = blockIdx.x; img < a.batch; img += gridDim.x, ++it_no) {
+    // One image.  Instantiated twice: a peeled first image, where the weight loads are still in flight and
+    // are waited for as each layer first needs them, and the steady-state loop, whose waits then cover only
+    // its own loads (one merged body made the compiler wait on the next image's frame loads in front of conv1).
+    auto process = [&](int img) __attribute__((always_inline)) {
         STACK_STAMP(a.prof, it_no, 0)
         __syncthreads();                    // previous image fully consumed (a2s aliases the patch)
         patch_commit<7, H * W / 16, PLANE - H * W>(pr, frame_bytes, patch, tid);
         __syncthreads();
         STACK_STAMP(a.prof, it_no, 1)
-        if (img + (int)gridDim.x < a.batch)
-            patch_issue<7>(pr, a.frames[grp], a.idx[grp], frame_bytes, img + gridDim.x, tid);
+        // unconditional (past the end: frame_index clamps to image 0): a conditional issue leaves the
+        // compiler merging old and new registers with copies that wait for the loads on the spot
+        if constexpr (MULTI) {
+            patch_issue_at<7>(pr, a.frames[grp] + f_nxt * frame_bytes, frame_bytes, tid);
+            f_nxt = frame_index(a.idx[grp], img + 2 * G, a.batch);     // consumed one image from now
+        }
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) { pin_agpr(wf1[ks][0]); pin_agpr(wf1[ks][1]); }
 
         // ---- conv1: 8x8 s4, 32 channels -> a1s (25 row blocks of 16 pixels, exactly; wave w takes w, w + 4, ..)
         // Pixel fragment of lane (pixel l15, g4): channel g4, kernel row ks, kx 0..7 = 16 bytes at an 8-byte
-        // aligned address (one ds_read2_b64).  Pixel m sits at dword 2 m + 128 oy of its row set, so 16
-        // consecutive pixels cover 32 distinct banks whatever rows they span: conflict-free.
+        // aligned address, as two ds_read_b64.  Pixel m sits at dword 2 m + 128 oy of its row set, so 16
+        // consecutive pixels cover 32 distinct banks whatever rows they span, and with the plane pitch
+        // == 32 (mod 64) dwords the other channel of a 32-lane group takes the other 32: conflict-free.
         // Software pipeline over row blocks (fully unrolled): the fragments of block i + 1 are fetched and
         // the outputs of block i - 1 are scaled / packed / stored in the shadow of block i's MFMAs.
         {
-            auto load1 = [&](bf16x8 (&xf)[KS1], int rb) {
-                int m = rb * 16 + l15;
-                int oy = m / OW1, ox = m - oy * OW1;
-                const bf16_t* base = patch + g4 * PLANE + (4 * oy) * W + 4 * ox;
+            auto load1 = [&](bf16x8 (&xf)[KS1], int it) {
+                const bf16_t* base = lds + ld1[it];
 #pragma unroll
-                for (int ks = 0; ks < KS1; ++ks) xf[ks] = patch_frag(base + ks * W);
+                for (int ks = 0; ks < KS1; ++ks) {     // two ds_read_b64 (kept apart: see lds_v2)
+                    u32x2 lo = *(lds_v2)(base + ks * W), hi = *(lds_v2)(base + ks * W + 4);
+                    xf[ks] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                }
             };
             auto mul1 = [&](const bf16x8 (&xf)[KS1], f32x4& c0, f32x4& c1) {
                 c0 = zero4; c1 = zero4;
@@ -392,37 +478,34 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
                     c1 = mfma_wx(wf1[ks][1], xf[ks], c1);
                 }
             };
-            auto store1 = [&](const f32x4& c0, const f32x4& c1, int rb) {
-                int pix = rb * 16 + l15;
-                int y = pix / OW1, x = pix - y * OW1;
-                bf16_t* dst = a1s + y * F1_RP + x * F1_CP + 4 * g4;
+            auto store1 = [&](const f32x4& c0, const f32x4& c1, int it) {
+                bf16_t* dst = lds + st1[it];
                 *reinterpret_cast<uint2*>(dst) = relu_pack4(c0, a.scale, b10);
                 *reinterpret_cast<uint2*>(dst + 16) = relu_pack4(c1, a.scale, b11);
             };
             bf16x8 xa[KS1], xb[KS1];
             f32x4 ca0, ca1, cb0, cb1;
-            load1(xa, wave);
+            load1(xa, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int it = 0; it < 6; ++it) {            // row blocks wave + 4 it <= 23: every wave has them
-                const int rb = wave + 4 * it;
                 auto& cur = (it & 1) ? xb : xa;
                 auto& nxt = (it & 1) ? xa : xb;
-                if (it < 5) load1(nxt, rb + 4);
-                else if (wave == 0) load1(nxt, 24);     // the 25th block is wave 0's
+                if (it < 5) load1(nxt, it + 1);
+                else if (wave == 0) load1(nxt, 6);      // the 25th block is wave 0's
                 if (it & 1) mul1(cur, cb0, cb1); else mul1(cur, ca0, ca1);
-                if (it > 0) { if (it & 1) store1(ca0, ca1, rb - 4); else store1(cb0, cb1, rb - 4); }
-                STACK_SCHED(2 * KS1, 1, 2, 4)
+                if (it > 0) { if (it & 1) store1(ca0, ca1, it - 1); else store1(cb0, cb1, it - 1); }
+                STACK_SCHED(2 * KS1, 1, 1, 2)
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (wave == 0) {
                 mul1(xa, ca0, ca1);                     // it = 6
-                store1(cb0, cb1, 20);
+                store1(cb0, cb1, 5);
                 STACK_SCHED(2 * KS1, 0, 2, 4)
                 __builtin_amdgcn_sched_barrier(0);
-                store1(ca0, ca1, 24);
+                store1(ca0, ca1, 6);
             } else {
-                store1(cb0, cb1, wave + 20);
+                store1(cb0, cb1, 5);
             }
         }
         STACK_STAMP(a.prof, it_no, 2)
@@ -430,33 +513,23 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
         STACK_STAMP(a.prof, it_no, 3)
         if (a.a1[grp]) {                    // coalesced copy-out for the backward pass (4 x 16 B per pixel)
             uint4* dst = reinterpret_cast<uint4*>(a.a1[grp] + (long)img * P1 * 32);
-            auto a1_chunk = [&](int t) {
-                int pix = t >> 2;
-                int y = pix / OW1, x = pix - y * OW1;
-                return *reinterpret_cast<const uint4*>(a1s + y * F1_RP + x * F1_CP + (t & 3) * 8);
-            };
-            uint4 v0 = a1_chunk(tid), v1 = a1_chunk(tid + 256), v2 = a1_chunk(tid + 512), v3 = a1_chunk(tid + 768),
-                  v4 = a1_chunk(tid + 1024), v5 = a1_chunk(tid + 1280);
+            auto a1_chunk = [&](int i) { return *reinterpret_cast<const uint4*>(lds + co1[i]); };
+            uint4 v0 = a1_chunk(0), v1 = a1_chunk(1), v2 = a1_chunk(2), v3 = a1_chunk(3), v4 = a1_chunk(4),
+                  v5 = a1_chunk(5);
             dst[tid] = v0; dst[tid + 256] = v1; dst[tid + 512] = v2; dst[tid + 768] = v3;
             dst[tid + 1024] = v4; dst[tid + 1280] = v5;
-            if (tid < P1 * 4 - 1536) dst[tid + 1536] = a1_chunk(tid + 1536);
+            if (tid < P1 * 4 - 1536) dst[tid + 1536] = a1_chunk(6);
         }
         STACK_STAMP(a.prof, it_no, 4)
-        if (!pinned) {
 #pragma unroll
-            for (int ks = 0; ks < KS2; ++ks) pin_agpr(wf2[ks]);
+        for (int ks = 0; ks < KS2; ++ks) pin_agpr(wf2[ks]);
 #pragma unroll
-            for (int ks = 0; ks < KS3; ++ks) pin_agpr(wf3[ks]);
-            pinned = true;
-        }
+        for (int ks = 0; ks < KS3; ++ks) pin_agpr(wf3[ks]);
         STACK_STAMP(a.prof, it_no, 5)
         // ---- conv2: 4x4 s2, 32 -> 64; wave w computes output channels [16 w, 16 w + 16) -> a2s
         {
             auto load2 = [&](bf16x8 (&xf)[KS2], int rb) {
-                int m = rb * 16 + l15;
-                int mm = m < P2 ? m : 0;
-                int oy = mm / OW2, ox = mm - oy * OW2;
-                const bf16_t* base = a1s + (2 * oy) * F1_RP + (2 * ox) * F1_CP + g4 * 8;
+                const bf16_t* base = lds + ld2[rb];
 #pragma unroll
                 for (int ks = 0; ks < KS2; ++ks)        // one tap (ky, kx) = 32 channels per k-step
                     xf[ks] = *reinterpret_cast<const bf16x8*>(base + (ks >> 2) * F1_RP + (ks & 3) * F1_CP);
@@ -470,12 +543,7 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
                 }
             };
             auto store2 = [&](const f32x4& c0, const f32x4& c1, int rb) {
-                int pix = rb * 16 + l15;
-                if (pix < P2) {
-                    int y = pix / OW2, x = pix - y * OW2;
-                    *reinterpret_cast<uint2*>(a2s + y * F2_RP + x * F2_CP + wave * 16 + 4 * g4) =
-                        relu_pack4(c0 + c1, 1.f, b2v);
-                }
+                if (rb * 16 + l15 < P2) *reinterpret_cast<uint2*>(lds + st2[rb]) = relu_pack4(c0 + c1, 1.f, b2v);
             };
             bf16x8 xa[KS2], xb[KS2];
             f32x4 ca0, ca1, cb0, cb1;
@@ -498,24 +566,17 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
         STACK_STAMP(a.prof, it_no, 7)
         if (a.a2[grp]) {
             uint4* dst = reinterpret_cast<uint4*>(a.a2[grp] + (long)img * P2 * 64);
-            auto a2_chunk = [&](int t) {
-                int pix = t >> 3;
-                int y = pix / OW2, x = pix - y * OW2;
-                return *reinterpret_cast<const uint4*>(a2s + y * F2_RP + x * F2_CP + (t & 7) * 8);
-            };
-            uint4 v0 = a2_chunk(tid), v1 = a2_chunk(tid + 256);
+            auto a2_chunk = [&](int i) { return *reinterpret_cast<const uint4*>(lds + co2[i]); };
+            uint4 v0 = a2_chunk(0), v1 = a2_chunk(1);
             dst[tid] = v0; dst[tid + 256] = v1;
-            if (tid < P2 * 8 - 512) dst[tid + 512] = a2_chunk(tid + 512);
+            if (tid < P2 * 8 - 512) dst[tid + 512] = a2_chunk(2);
         }
         STACK_STAMP(a.prof, it_no, 8)
         // ---- conv3: 3x3 s1, 64 -> 64 -> global a3 [(img, pix)][64]
         {
             bf16_t* out3 = a.a3[grp] + (long)img * P3 * 64;
             auto load3 = [&](bf16x8 (&xf)[KS3], int rb) {
-                int m = rb * 16 + l15;
-                int mm = m < P3 ? m : 0;
-                int oy = mm / OW3, ox = mm - oy * OW3;
-                const bf16_t* base = a2s + oy * F2_RP + ox * F2_CP + g4 * 8;
+                const bf16_t* base = lds + ld3[rb];
 #pragma unroll
                 for (int ks = 0; ks < KS3; ++ks) {      // tap = ks / 2, channel half = ks % 2
                     int tap = ks >> 1, ky = tap / 3, kx = tap - 3 * ky;
@@ -531,9 +592,7 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
                 }
             };
             auto store3 = [&](const f32x4& c0, const f32x4& c1, int rb) {
-                int pix = rb * 16 + l15;
-                if (pix < P3)
-                    *reinterpret_cast<uint2*>(out3 + (long)pix * 64 + wave * 16 + 4 * g4) = relu_pack4(c0 + c1, 1.f, b3v);
+                if (rb * 16 + l15 < P3) *reinterpret_cast<uint2*>(out3 + st3[rb]) = relu_pack4(c0 + c1, 1.f, b3v);
             };
             bf16x8 xa[KS3], xb[KS3];
             f32x4 ca0, ca1, cb0, cb1;
@@ -552,6 +611,13 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
             if ((NRB3 - 1) & 1) store3(cb0, cb1, NRB3 - 1); else store3(ca0, ca1, NRB3 - 1);
         }
         STACK_STAMP(a.prof, it_no, 9)
+        ++it_no;
+    };
+    int img = blockIdx.x;
+    if (img < a.batch) {
+        process(img);
+        if constexpr (MULTI)
+            for (img += G; img < a.batch; img += G) process(img);
     }
 }
 
@@ -816,12 +882,17 @@ PDA_EXPORT void pda_cnn_fwd_stack(const void* const* frames, const void* const* 
     size_t lds = ((size_t)4 * FWD_PLANE + (size_t)20 * F1_RP) * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_fwd_stack_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_fwd_stack_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_fwd_stack_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    int blocks = batch < 256 ? batch : 256;         // one workgroup per CU (88 KB LDS), looping over images
-    hipLaunchKernelGGL(cnn_fwd_stack_kernel, dim3(blocks, ngroups), dim3(256), lds, stream, a);
+    int blocks = batch < 256 ? batch : 256;         // one workgroup per CU (89 KB LDS), looping over images
+    if (blocks < batch)
+        hipLaunchKernelGGL(cnn_fwd_stack_kernel<true>, dim3(blocks, ngroups), dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL(cnn_fwd_stack_kernel<false>, dim3(blocks, ngroups), dim3(256), lds, stream, a);
 }
 
 // conv3^T -> relu'(a2) -> conv2^T -> relu'(a1): the data gradients da2 [(b, 9x9)][64] and da1 [(b, 20x20)][32]

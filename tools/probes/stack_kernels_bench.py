@@ -66,8 +66,6 @@ for B in (128, 1024):
                          [a1, None], [a2, None], [a3, a3], B, 84, 84, 4, 1 / 255.)
         torch.cuda.synchronize()
         L.pda_cnn_stack_prof(ctypes.c_void_p(0))
-    fine = prof.cpu()[64:64 + 21]
-    print('conv1 fine stamps (image 1):', [int(v - fine[0]) for v in fine])
     p = prof.cpu()[:64].view(4, 16)
     names = ["loop top", "committed", "conv1 done", "barrier", "a1 out", "pinned", "conv2 done", "barrier", "a2 out", "conv3 done"]
     for it in range(4):
