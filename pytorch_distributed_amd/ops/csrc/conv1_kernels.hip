@@ -635,29 +635,86 @@ struct DgradStackArgs {
     bf16_t* da2; bf16_t* da1; int batch;
 };
 
+// LDS plan (bf16 elements).  da3 and a2 / da2 live in zero-bordered 11 x 11 grids, so every tap of the two
+// transposed convolutions is a constant offset from the lane's base (no per-tap bounds test); pixel and row
+// pitches from tools/probes/lds_conflicts.py (4.6 - 4.7 LDS cycles per ds_read_b128, 4 = conflict-free).
+#define D1_CP 40        // a1 / da1: dense [400][32 + 8]
+#define D2_CP 80        // a2 / da2 grid, 1-pixel border
+#define D2_RP 928
+#define D3_CP 80        // da3 grid, 2-pixel border
+#define D3_RP 976
+#define D_A2OFF (400 * D1_CP)
+#define D_D3OFF (D_A2OFF + 11 * D2_RP)
+#define D_LDS_ELEMS (D_D3OFF + 11 * D3_RP)
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// keep the halves of val whose activation (bf16 bits) is > 0: relu'
+__device__ __forceinline__ uint32_t relu_gate2(uint32_t act, uint32_t val) {
+    s16x2 pos = __builtin_bit_cast(s16x2, act) > (s16x2){0, 0};
+    return val & __builtin_bit_cast(uint32_t, pos);
+}
+__device__ __forceinline__ uint2 gate_pack4(uint2 act, f32x4 v) {
+    return make_uint2(relu_gate2(act.x, pack2bf(v[0], v[1])), relu_gate2(act.y, pack2bf(v[2], v[3])));
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct DgradRegs { u32x4 a1[7], a2[3], d3[2]; };    // one image's inputs in flight: 1600 + 648 + 392 16-byte chunks
+
+__device__ __forceinline__ void dgrad_issue(DgradRegs& r, const DgradStackArgs& a, int img, int tid) {
+    const u32x4* s1 = reinterpret_cast<const u32x4*>(a.a1 + (long)img * 400 * 32);
+    const u32x4* s2 = reinterpret_cast<const u32x4*>(a.a2 + (long)img * 81 * 64);
+    const u32x4* s3 = reinterpret_cast<const u32x4*>(a.da3 + (long)img * 49 * 64);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { int t = tid + i * 256; r.a1[i] = s1[t < 1600 ? t : 0]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { int t = tid + i * 256; r.a2[i] = s2[t < 648 ? t : 0]; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { int t = tid + i * 256; r.d3[i] = s3[t < 392 ? t : 0]; }
+}
+
+// MULTI: workgroups loop over images with the next image's inputs prefetched into registers.
+template <bool MULTI>
 __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-    constexpr int P1 = 400, W1 = 20, P2 = 81, W2 = 9, P3 = 49, W3 = 7;
+    constexpr int P1 = 400, P2 = 81, P3 = 49, NRB3 = 6, NRB2 = 7;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, l15 = lane & 15;
+    const int G = gridDim.x;
 
-    // ---- weights: per-tap [o][c] tiles (T layout) -> B fragments
-    bf16x8 wf3[18];         // conv3^T: this wave's 16 input channels (nb = wave); k-step = (tap, o half)
+    DgradRegs in;
+    int img = blockIdx.x;
+    dgrad_issue(in, a, img < a.batch ? img : 0, tid);       // flies under the weight staging
+
+    // ---- weights: per-tap [o][c] tiles (T layout) -> fragments with rows = input channel, k = output channel
+    bf16x8 wf3[18];         // conv3^T: this wave's 16 input channels; k-step = (tap, o half)
     bf16x8 wf2[8][2];       // conv2^T: this wave's parity class; (tap a,b ; o half) x 2 channel blocks
-    for (int t = tid; t < 9 * 64 * 8; t += 256) {
-        int rg = t & 7, o = (t >> 3) & 63, tap = t >> 9;
-        uint4 v = *reinterpret_cast<const uint4*>(a.w3 + (long)o * 576 + tap * 64 + rg * 8);
-        *reinterpret_cast<uint4*>(lds + tap * 4096 + o * 64 + (((2 * rg) ^ swz_t<64>(o)) << 2)) = v;
-    }
-    __syncthreads();
+    {   // all 34 chunk loads of a thread are in flight together (a load -> store loop pays the L2 latency per trip)
+        u32x4 r3[18], r2[16];
 #pragma unroll
-    for (int ks = 0; ks < 18; ++ks)
-        wf3[ks] = read_frag<true, 64, 32>(lds + (ks >> 1) * 4096, wave * 16, ks & 1, lane);
-    __syncthreads();
-    for (int t = tid; t < 16 * 64 * 4; t += 256) {
-        int rg = t & 3, o = (t >> 2) & 63, tap = t >> 8;
-        uint4 v = *reinterpret_cast<const uint4*>(a.w2 + (long)o * 512 + tap * 32 + rg * 8);
-        *reinterpret_cast<uint4*>(lds + tap * 2048 + o * 32 + (((2 * rg) ^ swz_t<32>(o)) << 2)) = v;
+        for (int i = 0; i < 18; ++i) {
+            int t = tid + i * 256, rg = t & 7, o = (t >> 3) & 63, tap = t >> 9;
+            r3[i] = *reinterpret_cast<const u32x4*>(a.w3 + (long)o * 576 + tap * 64 + rg * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int t = tid + i * 256, rg = t & 3, o = (t >> 2) & 63, tap = t >> 8;
+            r2[i] = *reinterpret_cast<const u32x4*>(a.w2 + (long)o * 512 + tap * 32 + rg * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            int t = tid + i * 256, rg = t & 7, o = (t >> 3) & 63, tap = t >> 9;
+            *reinterpret_cast<u32x4*>(lds + tap * 4096 + o * 64 + (((2 * rg) ^ swz_t<64>(o)) << 2)) = r3[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks)
+            wf3[ks] = read_frag<true, 64, 32>(lds + (ks >> 1) * 4096, wave * 16, ks & 1, lane);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int t = tid + i * 256, rg = t & 3, o = (t >> 2) & 63, tap = t >> 8;
+            *reinterpret_cast<u32x4*>(lds + tap * 2048 + o * 32 + (((2 * rg) ^ swz_t<32>(o)) << 2)) = r2[i];
+        }
     }
     __syncthreads();
     const int py = wave >> 1, px = wave & 1;
@@ -669,142 +726,179 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
         for (int nb = 0; nb < 2; ++nb) wf2[t][nb] = read_frag<true, 32, 32>(lds + tap * 2048, nb * 16, half, lane);
     }
 #pragma unroll
-    for (int ks = 0; ks < 18; ++ks) pin_agpr(wf3[ks]);      // B operands live in the accumulation registers
+    for (int ks = 0; ks < 18; ++ks) pin_agpr(wf3[ks]);      // MFMA operands straight from the accumulation registers
 #pragma unroll
     for (int t = 0; t < 8; ++t) { pin_agpr(wf2[t][0]); pin_agpr(wf2[t][1]); }
     __syncthreads();
+    // the two grids start out all zero; images only ever write their interiors
+    for (int t = tid; t < (D_LDS_ELEMS - D_A2OFF) / 8; t += 256)
+        *reinterpret_cast<uint4*>(lds + D_A2OFF + t * 8) = make_uint4(0, 0, 0, 0);
 
-    bf16_t* a1m = lds;                              // [P1][A1_PITCH]   a1, then da1 in place
-    bf16_t* a2m = a1m + P1 * A1_PITCH;              // [P2 + 1][A2_PITCH] a2, then da2 in place; row P2 stays zero
-    bf16_t* d3 = a2m + (P2 + 1) * A2_PITCH;         // [P3 + 1][A2_PITCH] da3; row P3 stays zero
-    for (int t = tid; t < A2_PITCH; t += 256) {
-        a2m[P2 * A2_PITCH + t] = 0;
-        d3[P3 * A2_PITCH + t] = 0;
+    // ---- per-lane LDS offsets (elements), opaque so the divisions stay out of the phases
+    int in1[7], in2[3], in3[2];             // where the input chunks land (and the gradients leave from)
+    int ld3[NRB3], st3[NRB3], ld2[NRB2], st2[NRB2];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        int t = tid + i * 256;
+        t = t < P1 * 4 ? t : 0;
+        in1[i] = (t >> 2) * D1_CP + (t & 3) * 8;
+        asm volatile("" : "+v"(in1[i]));
     }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int t = tid + i * 256;
+        t = t < P2 * 8 ? t : 0;
+        int pix = t >> 3, y = pix / 9, x = pix - 9 * y;
+        in2[i] = D_A2OFF + (y + 1) * D2_RP + (x + 1) * D2_CP + (t & 7) * 8;
+        asm volatile("" : "+v"(in2[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int t = tid + i * 256;
+        t = t < P3 * 8 ? t : 0;
+        int pix = t >> 3, y = pix / 7, x = pix - 7 * y;
+        in3[i] = D_D3OFF + (y + 2) * D3_RP + (x + 2) * D3_CP + (t & 7) * 8;
+        asm volatile("" : "+v"(in3[i]));
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB3; ++rb) {
+        int m = rb * 16 + l15;
+        m = m < P2 ? m : 0;
+        int iy = m / 9, ix = m - 9 * iy;
+        ld3[rb] = D_D3OFF + (iy + 2) * D3_RP + (ix + 2) * D3_CP + g4 * 8;
+        st3[rb] = D_A2OFF + (iy + 1) * D2_RP + (ix + 1) * D2_CP + wave * 16 + 4 * g4;
+        asm volatile("" : "+v"(ld3[rb]), "+v"(st3[rb]));
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB2; ++rb) {
+        int q = rb * 16 + l15;
+        q = q < 100 ? q : 0;
+        int iy2 = q / 10, ix2 = q - 10 * iy2;
+        ld2[rb] = D_A2OFF + (iy2 + 1) * D2_RP + (ix2 + 1) * D2_CP + g4 * 8;
+        st2[rb] = ((2 * iy2 + py) * 20 + 2 * ix2 + px) * D1_CP + 4 * g4;
+        asm volatile("" : "+v"(ld2[rb]), "+v"(st2[rb]));
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    for (int img = blockIdx.x; img < a.batch; img += gridDim.x) {
+    auto process = [&](int img) __attribute__((always_inline)) {
+        __syncthreads();                    // previous image's gradients have left (and the grids are zeroed)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(lds + in1[i]) = in.a1[i];
+        if (tid < P1 * 4 - 1536) *reinterpret_cast<u32x4*>(lds + in1[6]) = in.a1[6];
+        *reinterpret_cast<u32x4*>(lds + in2[0]) = in.a2[0];
+        *reinterpret_cast<u32x4*>(lds + in2[1]) = in.a2[1];
+        if (tid < P2 * 8 - 512) *reinterpret_cast<u32x4*>(lds + in2[2]) = in.a2[2];
+        *reinterpret_cast<u32x4*>(lds + in3[0]) = in.d3[0];
+        if (tid < P3 * 8 - 256) *reinterpret_cast<u32x4*>(lds + in3[1]) = in.d3[1];
         __syncthreads();
+        if constexpr (MULTI) dgrad_issue(in, a, img + G < a.batch ? img + G : 0, tid);   // unconditional: see cnn_fwd_stack_kernel
+
+        // ---- conv3^T: da2[(iy,ix)][c] = sum_{tap,o} w3[o][tap][c] da3[(iy-ky, ix-kx)][o], times relu'(a2).
+        // Swapped product (weights as the A operand): a lane ends with 4 consecutive channels of one pixel.
         {
-            const uint4* s1 = reinterpret_cast<const uint4*>(a.a1 + (long)img * P1 * 32);
-            for (int t = tid; t < P1 * 4; t += 256)
-                *reinterpret_cast<uint4*>(a1m + (t >> 2) * A1_PITCH + (t & 3) * 8) = s1[t];
-            const uint4* s2 = reinterpret_cast<const uint4*>(a.a2 + (long)img * P2 * 64);
-            for (int t = tid; t < P2 * 8; t += 256)
-                *reinterpret_cast<uint4*>(a2m + (t >> 3) * A2_PITCH + (t & 7) * 8) = s2[t];
-            const uint4* s3 = reinterpret_cast<const uint4*>(a.da3 + (long)img * P3 * 64);
-            for (int t = tid; t < P3 * 8; t += 256)
-                *reinterpret_cast<uint4*>(d3 + (t >> 3) * A2_PITCH + (t & 7) * 8) = s3[t];
-        }
-        __syncthreads();
-        // ---- conv3^T: da2[(iy,ix)][c] = sum_{tap,o} da3[(iy-ky, ix-kx)][o] w3[o][tap][c], times relu'(a2)
-        // (fragments of row block i + 1 in flight under the MFMAs of row block i, as in the forward kernel)
-        {
-            auto load3 = [&](bf16x8 (&af)[18], int rb) {
-                int p = rb * 16 + l15;
-                int pp = p < P2 ? p : 0;
-                int iy = pp / W2, ix = pp - iy * W2;
+            auto load = [&](bf16x8 (&xf)[18], int rb) {
+                const bf16_t* base = lds + ld3[rb];
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     int ky = tap / 3, kx = tap - 3 * ky;
-                    int oy = iy - ky, ox = ix - kx;
-                    bool ok = oy >= 0 && oy < W3 && ox >= 0 && ox < W3;
-                    const bf16_t* src = d3 + (ok ? oy * W3 + ox : P3) * A2_PITCH + g4 * 8;
-                    af[2 * tap] = *reinterpret_cast<const bf16x8*>(src);
-                    af[2 * tap + 1] = *reinterpret_cast<const bf16x8*>(src + 32);
+                    xf[2 * tap] = *reinterpret_cast<const bf16x8*>(base - ky * D3_RP - kx * D3_CP);
+                    xf[2 * tap + 1] = *reinterpret_cast<const bf16x8*>(base - ky * D3_RP - kx * D3_CP + 32);
                 }
             };
-            bf16x8 afa[18], afb[18];
-            load3(afa, 0);
-#pragma unroll
-            for (int rb = 0; rb < (P2 + 15) / 16; ++rb) {
-                auto& cur = (rb & 1) ? afb : afa;
-                auto& nxt = (rb & 1) ? afa : afb;
-                if (rb + 1 < (P2 + 15) / 16) load3(nxt, rb + 1);
-                bf16_t mask[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int pix = rb * 16 + g4 * 4 + r;
-                    mask[r] = a2m[(pix < P2 ? pix : P2) * A2_PITCH + wave * 16 + l15];  // this wave's columns only
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            auto mul = [&](const bf16x8 (&xf)[18], f32x4& c0, f32x4& c1) {
+                c0 = zero4; c1 = zero4;
 #pragma unroll
                 for (int ks = 0; ks < 18; ks += 2) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[ks], wf3[ks], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[ks + 1], wf3[ks + 1], acc1, 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int pix = rb * 16 + g4 * 4 + r;
-                    if (pix < P2)
-                        a2m[pix * A2_PITCH + wave * 16 + l15] = (bf2f(mask[r]) > 0.f) ? f2bf(acc0[r] + acc1[r]) : (bf16_t)0;
-                }
-            }
-        }
-        __syncthreads();                    // a2m now holds da2
-        {
-            uint4* dst = reinterpret_cast<uint4*>(a.da2 + (long)img * P2 * 64);
-            for (int t = tid; t < P2 * 8; t += 256)
-                dst[t] = *reinterpret_cast<const uint4*>(a2m + (t >> 3) * A2_PITCH + (t & 7) * 8);
-        }
-        // ---- conv2^T for this wave's parity class: input pixel (2 iy2 + py, 2 ix2 + px), taps (py + 2a, px + 2b)
-        {
-            auto load2 = [&](bf16x8 (&af)[8], int rb) {
-                int q = rb * 16 + l15;
-                int qq = q < 100 ? q : 0;
-                int iy2 = qq / 10, ix2 = qq - iy2 * 10;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    int oy = iy2 - (t >> 1), ox = ix2 - (t & 1);
-                    bool ok = oy >= 0 && oy < W2 && ox >= 0 && ox < W2;
-                    const bf16_t* src = a2m + (ok ? oy * W2 + ox : P2) * A2_PITCH + g4 * 8;
-                    af[2 * t] = *reinterpret_cast<const bf16x8*>(src);
-                    af[2 * t + 1] = *reinterpret_cast<const bf16x8*>(src + 32);
+                    c0 = mfma_wx(wf3[ks], xf[ks], c0);
+                    c1 = mfma_wx(wf3[ks + 1], xf[ks + 1], c1);
                 }
             };
-            bf16x8 afa[8], afb[8];
-            load2(afa, 0);
-#pragma unroll
-            for (int rb = 0; rb < (100 + 15) / 16; ++rb) {
-                auto& cur = (rb & 1) ? afb : afa;
-                auto& nxt = (rb & 1) ? afa : afb;
-                if (rb + 1 < (100 + 15) / 16) load2(nxt, rb + 1);
-                bf16_t* cell[4];
-                bf16_t m0[4], m1[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int qr = rb * 16 + g4 * 4 + r;
-                    int qc = qr < 100 ? qr : 0;
-                    int y2 = qc / 10, x2 = qc - y2 * 10;
-                    cell[r] = a1m + ((2 * y2 + py) * W1 + 2 * x2 + px) * A1_PITCH + l15;   // this class's pixels only
-                    m0[r] = cell[r][0];
-                    m1[r] = cell[r][16];
+            auto store = [&](const f32x4& c0, const f32x4& c1, int rb) {
+                if (rb * 16 + l15 < P2) {
+                    uint2* cell = reinterpret_cast<uint2*>(lds + st3[rb]);      // this wave's channels only
+                    *cell = gate_pack4(*cell, c0 + c1);
                 }
+            };
+            bf16x8 xa[18], xb[18];
+            f32x4 ca0, ca1, cb0, cb1;
+            load(xa, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rb = 0; rb < NRB3; ++rb) {
+                auto& cur = (rb & 1) ? xb : xa;
+                auto& nxt = (rb & 1) ? xa : xb;
+                if (rb + 1 < NRB3) load(nxt, rb + 1);
+                if (rb & 1) mul(cur, cb0, cb1); else mul(cur, ca0, ca1);
+                if (rb > 0) { if (rb & 1) store(ca0, ca1, rb - 1); else store(cb0, cb1, rb - 1); }
+                STACK_SCHED(18, 1, 1, 2)
                 __builtin_amdgcn_sched_barrier(0);
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            }
+            if ((NRB3 - 1) & 1) store(cb0, cb1, NRB3 - 1); else store(ca0, ca1, NRB3 - 1);
+        }
+        __syncthreads();                    // the a2 grid now holds da2
+        {
+            uint4* dst = reinterpret_cast<uint4*>(a.da2 + (long)img * P2 * 64);
+            uint4 v0 = *reinterpret_cast<const uint4*>(lds + in2[0]), v1 = *reinterpret_cast<const uint4*>(lds + in2[1]);
+            dst[tid] = v0; dst[tid + 256] = v1;
+            if (tid < P2 * 8 - 512) dst[tid + 512] = *reinterpret_cast<const uint4*>(lds + in2[2]);
+        }
+        // ---- conv2^T for this wave's parity class: input pixel (2 iy2 + py, 2 ix2 + px), taps (py + 2a, px + 2b)
+        // read da2 at (iy2 - a, ix2 - b); both 16-channel blocks of a1 per fragment
+        {
+            auto load = [&](bf16x8 (&xf)[8], int rb) {
+                const bf16_t* base = lds + ld2[rb];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    xf[2 * t] = *reinterpret_cast<const bf16x8*>(base - (t >> 1) * D2_RP - (t & 1) * D2_CP);
+                    xf[2 * t + 1] = *reinterpret_cast<const bf16x8*>(base - (t >> 1) * D2_RP - (t & 1) * D2_CP + 32);
+                }
+            };
+            auto mul = [&](const bf16x8 (&xf)[8], f32x4& c0, f32x4& c1) {
+                c0 = zero4; c1 = zero4;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[t], wf2[t][0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[t], wf2[t][1], acc1, 0, 0, 0);
+                    c0 = mfma_wx(wf2[t][0], xf[t], c0);
+                    c1 = mfma_wx(wf2[t][1], xf[t], c1);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto store = [&](const f32x4& c0, const f32x4& c1, int rb) {
+                if (rb * 16 + l15 < 100) {
+                    uint2* cell = reinterpret_cast<uint2*>(lds + st2[rb]);      // this class's pixels only
+                    cell[0] = gate_pack4(cell[0], c0);
+                    cell[4] = gate_pack4(cell[4], c1);                          // + 16 channels
+                }
+            };
+            bf16x8 xa[8], xb[8];
+            f32x4 ca0, ca1, cb0, cb1;
+            load(xa, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int qr = rb * 16 + g4 * 4 + r;
-                    if (qr < 100) {
-                        cell[r][0] = (bf2f(m0[r]) > 0.f) ? f2bf(acc0[r]) : (bf16_t)0;
-                        cell[r][16] = (bf2f(m1[r]) > 0.f) ? f2bf(acc1[r]) : (bf16_t)0;
-                    }
-                }
+            for (int rb = 0; rb < NRB2; ++rb) {
+                auto& cur = (rb & 1) ? xb : xa;
+                auto& nxt = (rb & 1) ? xa : xb;
+                if (rb + 1 < NRB2) load(nxt, rb + 1);
+                if (rb & 1) mul(cur, cb0, cb1); else mul(cur, ca0, ca1);
+                if (rb > 0) { if (rb & 1) store(ca0, ca1, rb - 1); else store(cb0, cb1, rb - 1); }
+                STACK_SCHED(16, 1, 2, 4)
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if ((NRB2 - 1) & 1) store(cb0, cb1, NRB2 - 1); else store(ca0, ca1, NRB2 - 1);
         }
-        __syncthreads();                    // a1m now holds da1
+        __syncthreads();                    // the a1 rows now hold da1
         {
             uint4* dst = reinterpret_cast<uint4*>(a.da1 + (long)img * P1 * 32);
-            for (int t = tid; t < P1 * 4; t += 256)
-                dst[t] = *reinterpret_cast<const uint4*>(a1m + (t >> 2) * A1_PITCH + (t & 3) * 8);
+            uint4 v[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = *reinterpret_cast<const uint4*>(lds + in1[i]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dst[tid + i * 256] = v[i];
+            if (tid < P1 * 4 - 1536) dst[tid + 1536] = *reinterpret_cast<const uint4*>(lds + in1[6]);
         }
+    };
+    if (img < a.batch) {
+        process(img);
+        if constexpr (MULTI)
+            for (img += G; img < a.batch; img += G) process(img);
     }
 }
 
@@ -903,15 +997,19 @@ PDA_EXPORT void pda_cnn_dgrad_stack(const void* da3, const void* a2, const void*
                                     void* da2, void* da1, int batch, hipStream_t stream) {
     DgradStackArgs a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3,
                         (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch};
-    size_t work = ((size_t)400 * A1_PITCH + (size_t)82 * A2_PITCH + (size_t)50 * A2_PITCH) * 2;
-    size_t lds = 9 * 4096 * 2;          // the weight staging tiles are the larger tenant
-    if (work > lds) lds = work;
+    size_t lds = (size_t)D_LDS_ELEMS * 2;   // >= the 9 x 4096-element weight staging tiles
+    static_assert(D_LDS_ELEMS >= 9 * 4096, "weight staging must fit the working set's LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    int blocks = batch < 512 ? batch : 512;
-    hipLaunchKernelGGL(cnn_dgrad_stack_kernel, dim3(blocks), dim3(256), lds, stream, a);
+    int blocks = batch < 256 ? batch : 256;         // one workgroup per CU (a wave owns its SIMD's register file)
+    if (blocks < batch)
+        hipLaunchKernelGGL(cnn_dgrad_stack_kernel<true>, dim3(blocks), dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL(cnn_dgrad_stack_kernel<false>, dim3(blocks), dim3(256), lds, stream, a);
 }

@@ -54,3 +54,44 @@ if __name__ == "__main__":
     print("conv3 reads of a2 (9x9x64, stride 1): pitch dwords -> cycles/instr")
     for pitch in range(32, 57, 4):
         print("  pitch %2d: %.2f" % (pitch, layer("c3", 49, 7, 9, 1, taps3, pitch, [0, 4, 8, 12, 16, 20, 24, 28], halves=2)))
+
+
+def gather(nrows, row_w, src_of, taps, halves, RP, CP):
+    """generic: rows m -> (y, x) = divmod(m, row_w); src_of(y, x, tap) -> (sy, sx) in the stored grid;
+    lane (l15, g4) reads dword address sy*RP + sx*CP + 4*(g4 + 4*half)."""
+    tot = n = 0
+    for rb in range((nrows + 15) // 16):
+        for tap in taps:
+            for half in range(halves):
+                addrs = []
+                for lane in range(64):
+                    l15, g4 = lane & 15, lane >> 4
+                    m = rb * 16 + l15
+                    if m >= nrows:
+                        m = 0
+                    y, x = divmod(m, row_w)
+                    sy, sx = src_of(y, x, tap)
+                    addrs.append(sy * RP + sx * CP + 4 * (g4 + 4 * half))
+                tot += instr_cycles(addrs)
+                n += 1
+    return tot / n
+
+
+def search_dgrad():
+    """Backward (data-gradient) gathers over zero-bordered 11x11 grids of 64-channel pixels."""
+    taps3 = [(a, b) for a in range(3) for b in range(3)]
+    taps2 = [(a, b) for a in range(2) for b in range(2)]
+    res3, res2 = [], []
+    for CP in range(32, 49, 4):
+        for RP in range(11 * CP, 11 * CP + 68, 4):
+            c3 = gather(81, 9, lambda y, x, t: (y + 2 - t[0], x + 2 - t[1]), taps3, 2, RP, CP)
+            c2 = gather(100, 10, lambda y, x, t: (y + 1 - t[0], x + 1 - t[1]), taps2, 2, RP, CP)
+            res3.append((c3, CP, RP))
+            res2.append((c2, CP, RP))
+    res3.sort(); res2.sort()
+    print("conv3^T gathers of da3 (cycles, pixel pitch, row pitch in dwords):", res3[:6])
+    print("conv2^T gathers of da2:", res2[:6])
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "dgrad":
+    search_dgrad()
