@@ -30,14 +30,31 @@ struct DqnHeadArgs {
 template <int HID>
 __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
     constexpr int PER = HID / 64;       // values per lane (8 for 512)
+    const int wpb = blockDim.x >> 6;    // waves per workgroup: 1 for small batches (one sample per CU), else 4
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int b = blockIdx.x * 4 + wave;
+    int b = blockIdx.x * wpb + wave;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (p.rng_counter) *p.rng_counter += 1;     // the sampler of the NEXT step draws a fresh stream
         if (p.opt_step) *p.opt_step += 1;           // Adam of THIS step sees t = old + 1
     }
     if (b >= p.B) return;
     long row = (long)b * HID + lane * PER;
+
+    // The replay row (index -> tail record -> action -> that action's W5 row) is a chain of three dependent
+    // global loads.  It is started here, ahead of everything else and ahead of the zeroing stores below
+    // (which the compiler will not move loads across), so that it runs under the hidden-row loads and the
+    // dot products instead of after them.
+    const int ridx = p.idx ? p.idx[b] : b;
+    const float* tl = p.tails + (long)ridx * p.tail_ld;
+    const float t_act = tl[p.off_action], t_rew = tl[p.off_reward], t_gam = tl[p.off_gamma], t_term = tl[p.off_term];
+    const int act = min(max((int)t_act, 0), p.A - 1);
+    const float w = p.isw ? p.isw[b] : 1.f;
+    float wa[PER];
+    {
+        const float* w_act = p.w5_on + (long)act * HID + lane * PER;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) wa[j] = w_act[j];
+    }
 
     float h0[PER], ht[PER], hd[PER];
 #pragma unroll
@@ -93,21 +110,15 @@ __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
     }
     float next_q = p.h1pre_on1 ? __shfl(myqt, arg_d, 64) : best_t;
 
-    int ridx = p.idx ? p.idx[b] : b;
-    const float* tl = p.tails + (long)ridx * p.tail_ld;
-    int act = (int)tl[p.off_action];
-    act = min(max(act, 0), p.A - 1);
-    float y = tl[p.off_reward] + tl[p.off_gamma] * next_q * (1.f - tl[p.off_term]);
+    float y = t_rew + t_gam * next_q * (1.f - t_term);
     float td = __shfl(myq0, act, 64) - y;
-    float w = p.isw ? p.isw[b] : 1.f;
     float dqa = 2.f * w * td / (float)p.B;
 
-    const float* w_act = p.w5_on + (long)act * HID + lane * PER;
     uint32_t hw[PER / 2], dw[PER / 2];
 #pragma unroll
     for (int j = 0; j < PER; j += 2) {
         hw[j / 2] = pack2bf(h0[j], h0[j + 1]);
-        dw[j / 2] = pack2bf(h0[j] > 0.f ? dqa * w_act[j] : 0.f, h0[j + 1] > 0.f ? dqa * w_act[j + 1] : 0.f);
+        dw[j / 2] = pack2bf(h0[j] > 0.f ? dqa * wa[j] : 0.f, h0[j + 1] > 0.f ? dqa * wa[j + 1] : 0.f);
     }
     uint32_t* ho = reinterpret_cast<uint32_t*>(p.h1_on0 + row);
     uint32_t* dout = reinterpret_cast<uint32_t*>(p.dh1 + row);
@@ -131,7 +142,8 @@ __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
 
 PDA_EXPORT void pda_dqn_head(const DqnHeadArgs* args, hipStream_t stream) {
     DqnHeadArgs p = *args;
-    dim3 grid((p.B + 3) / 4), block(256);
+    const int wpb = p.B <= 1024 ? 1 : 4;
+    dim3 grid((p.B + wpb - 1) / wpb), block(64 * wpb);
     if (p.HID == 512) hipLaunchKernelGGL(dqn_head_kernel<512>, grid, block, 0, stream, p);
     else if (p.HID == 256) hipLaunchKernelGGL(dqn_head_kernel<256>, grid, block, 0, stream, p);
 }
@@ -143,7 +155,7 @@ template <int HID>
 __global__ __launch_bounds__(256) void act_head_kernel(ActHeadArgs p) {
     constexpr int PER = HID / 64;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int b = blockIdx.x * 4 + wave;
+    int b = blockIdx.x * (blockDim.x >> 6) + wave;   // 1 or 4 waves per workgroup, see the launcher
     if (b >= p.B) return;
     long row = (long)b * HID + lane * PER;
     float h[PER];
@@ -181,7 +193,8 @@ __global__ __launch_bounds__(256) void act_head_kernel(ActHeadArgs p) {
 
 PDA_EXPORT void pda_act_head(const ActHeadArgs* args, hipStream_t stream) {
     ActHeadArgs p = *args;
-    dim3 grid((p.B + 3) / 4), block(256);
+    const int wpb = p.B <= 1024 ? 1 : 4;
+    dim3 grid((p.B + wpb - 1) / wpb), block(64 * wpb);
     if (p.HID == 512) hipLaunchKernelGGL(act_head_kernel<512>, grid, block, 0, stream, p);
     else if (p.HID == 256) hipLaunchKernelGGL(act_head_kernel<256>, grid, block, 0, stream, p);
 }

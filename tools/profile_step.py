@@ -52,8 +52,10 @@ def main():
     ap.add_argument("--tag", default="step")
     ap.add_argument("--per", action="store_true")
     a = ap.parse_args()
-    out = os.path.join(ROOT, "gpurun_out", a.tag)
+    out = os.path.join(ROOT, "gpurun_out", a.tag)      # text summaries and pass logs (merged back by gpurun)
+    raw = os.path.join("/tmp", "pda_prof", a.tag)       # rocprofv3 databases: large, stay on the GPU box
     os.makedirs(out, exist_ok=True)
+    os.makedirs(raw, exist_ok=True)
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     env_tmp = "/tmp"
     os.environ["TMPDIR"] = env_tmp
@@ -63,7 +65,7 @@ def main():
     from rocpd_summary import short
 
     # pass 1: kernel trace
-    d = os.path.join(out, "trace")
+    d = os.path.join(raw, "trace")
     rc = run(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "t", "--"] + target, 240,
              os.path.join(out, "trace.log"))
     print("kernel-trace pass rc=%d" % rc, flush=True)
@@ -74,6 +76,7 @@ def main():
     with open(summary, "w") as fh:
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_summary.py"), db, "--steps", str(a.steps),
                         "--top", "30"], stdout=fh, cwd=ROOT)
+    shutil.copy(summary, os.path.join(out, os.path.basename(summary)))
     con = sqlite3.connect(db)
     durs = dict(con.execute("select name, sum(duration) from kernels group by name").fetchall())
     calls = dict(con.execute("select name, count(*) from kernels group by name").fetchall())
@@ -81,7 +84,7 @@ def main():
     # counter passes
     merged = {}
     for gname, ctrs in GROUPS.items():
-        d = os.path.join(out, "pmc_" + gname)
+        d = os.path.join(raw, "pmc_" + gname)
         rc = run(["timeout", "-s", "KILL", "120", "rocprofv3", "--pmc"] + ctrs + ["-d", d, "-o", "p", "--"] + target,
                  180, os.path.join(out, "pmc_%s.log" % gname))
         print("pmc pass %s rc=%d" % (gname, rc), flush=True)
