@@ -287,10 +287,10 @@ struct AdamExtras {
 __device__ __forceinline__ bool row_mode(const SegEntry& s) {
     return (s.flags & 1) && s.C > 1 && (s.P | 1) * s.C <= OPT_ROW_LDS;
 }
-// flags bit 1: "fine" flat chunks of one element per thread (segments whose gradient is summed from
-// many split-K slabs inside the optimizer: the slice loop must not also serialise over elements)
+// flags bit 1: "fine" flat chunks of 64 elements (segments whose gradient is summed from many split-K slabs
+// inside the optimizer): a lane per element, the slices dealt over the 4 waves of the workgroup
 __device__ __forceinline__ int chunk_len(const SegEntry& s) {
-    return row_mode(s) ? s.cols : ((s.flags & 2) ? 256 : OPT_CHUNK);
+    return row_mode(s) ? s.cols : ((s.flags & 2) ? 64 : OPT_CHUNK);
 }
 
 // gradient element e (kernel order within segment seg): the flat buffer, or the sum of the split-K slabs
@@ -347,6 +347,83 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         int r = ch.y / s.cols;
         float* prow = p + (long)s.start + (long)r * s.cols;
         int P = s.P, C = s.C, pitch = P | 1;
+        const long gbase0 = (long)s.start + (long)r * s.cols;
+        const long sbase0 = (long)s.shadow_off + (long)r * s.shadow_ld;
+        const bool summed = x.slab != nullptr && x.slabinfo[ch.x].y > 0;
+        if (!summed && ((C | s.cols | (int)gbase0 | (int)sbase0) & 3) == 0) {
+            // 16-byte path (fc1: 512 rows of 3136 = 95 % of the parameters).  Every load of a phase is issued
+            // before the first use: the scalar loops below make ~13 dependent round trips per row, which kept
+            // this launch at 3.4 TB/s.
+            constexpr int IT = (OPT_ROW_LDS + 1023) / 1024;
+            float4 a4[IT], m4[IT], v4[IT];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                int i = (threadIdx.x + it * 256) * 4;
+                if (i < s.cols) a4[it] = *reinterpret_cast<const float4*>(prow + i);
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                int i = (threadIdx.x + it * 256) * 4;
+                if (i < s.cols) {
+                    const float e4[4] = {a4[it].x, a4[it].y, a4[it].z, a4[it].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        int c = (i + k) / P, pp = (i + k) - c * P;
+                        row[c * pitch + pp] = e4[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {       // gradient / moments: kernel order, coalesced
+                int q = (threadIdx.x + it * 256) * 4;
+                if (q < s.cols) {
+                    a4[it] = *reinterpret_cast<const float4*>(g + gbase0 + q);
+                    m4[it] = *reinterpret_cast<const float4*>(m + gbase0 + q);
+                    v4[it] = *reinterpret_cast<const float4*>(v + gbase0 + q);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                int q = (threadIdx.x + it * 256) * 4;
+                if (q < s.cols) {
+                    int pp = q / C, c = q - pp * C;         // C % 4 == 0: the four share pp
+                    float gq[4] = {a4[it].x, a4[it].y, a4[it].z, a4[it].w};
+                    float mq[4] = {m4[it].x, m4[it].y, m4[it].z, m4[it].w};
+                    float vq[4] = {v4[it].x, v4[it].y, v4[it].z, v4[it].w};
+                    float pq[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float gi = fminf(fmaxf(gq[k] * gscale, -clip), clip);
+                        float pi = row[(c + k) * pitch + pp];
+                        gi += wd * pi;
+                        mq[k] = b1 * mq[k] + (1.f - b1) * gi;
+                        vq[k] = b2 * vq[k] + (1.f - b2) * gi * gi;
+                        pi -= step_size * mq[k] / (sqrtf(vq[k]) * inv_sqrt_bc2 + eps);
+                        row[(c + k) * pitch + pp] = pi;
+                        pq[k] = pi;
+                    }
+                    *reinterpret_cast<float4*>(m + gbase0 + q) = make_float4(mq[0], mq[1], mq[2], mq[3]);
+                    *reinterpret_cast<float4*>(v + gbase0 + q) = make_float4(vq[0], vq[1], vq[2], vq[3]);
+                    *reinterpret_cast<uint2*>(shadow + sbase0 + q) = make_uint2(pack2bf(pq[0], pq[1]), pack2bf(pq[2], pq[3]));
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                int i = (threadIdx.x + it * 256) * 4;
+                if (i < s.cols) {
+                    float e4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        int c = (i + k) / P, pp = (i + k) - c * P;
+                        e4[k] = row[c * pitch + pp];
+                    }
+                    *reinterpret_cast<float4*>(prow + i) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                }
+            }
+            return;
+        }
         for (int i = threadIdx.x; i < s.cols; i += 256) {
             int c = i / P, pp = i - c * P;
             row[c * pitch + pp] = prow[i];
@@ -375,6 +452,44 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         return;
     }
     int end = min(ch.y + chunk_len(s), s.count);
+    if ((s.flags & 2) && x.slab != nullptr && x.slabinfo[ch.x].y > 0) {
+        // Slab-summed segment: 64 elements per workgroup, wave w adds slices w, w + 4, .. with 8 loads in
+        // flight per lane, the four partial sums meet in LDS.  (One thread per element walking all the
+        // slices -- 256 of them for conv1 at batch 128 -- was a chain of ~64 dependent memory round trips
+        // on 32 workgroups: it set the duration of the whole launch.)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int e = ch.y + lane;
+        const bool ok = e < end;
+        const int4 sinfo = x.slabinfo[ch.x];
+        const float* q = x.slab + sinfo.x + (ok ? e : ch.y);
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+        int sl = wave;
+        for (; sl + 28 < sinfo.y; sl += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += q[(long)(sl + 4 * u) * sinfo.z];
+        }
+        for (; sl < sinfo.y; sl += 4) acc[0] += q[(long)sl * sinfo.z];
+        row[wave * 64 + lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        __syncthreads();
+        if (wave == 0 && ok) {
+            long si;
+            long ip = master_index(s, e, &si);
+            long i = (long)s.start + e;
+            float gi = (row[lane] + row[64 + lane]) + (row[128 + lane] + row[192 + lane]);
+            g[i] = gi;          // keep the flat gradient readable (tests, debugging)
+            gi = fminf(fmaxf(gi * gscale, -clip), clip);
+            float pi = p[ip];
+            gi += wd * pi;
+            float mi = b1 * m[i] + (1.f - b1) * gi;
+            float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+            pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+            p[ip] = pi; m[i] = mi; v[i] = vi;
+            if (si >= 0) shadow[si] = f2bf(pi);
+        }
+        return;
+    }
     for (int e = ch.y + threadIdx.x; e < end; e += 256) {
         long si;
         long ip = master_index(s, e, &si);

@@ -272,11 +272,13 @@ def test_dp_step_program_one_rank_rccl_equals_single(eng):
                 print("dp graph mode:", prog.dp_graph_mode)
                 assert prog.dp_graph_mode in ("whole", "split")
             flats.append((e.online.flat.clone(), e.target.flat.clone(), e.mean_loss()))
-        # fc1's forward split-K sums with fp32 atomics, so two runs differ in the last bits and
-        # Adam (g / |g|) amplifies that on near-zero gradients: compare with a tolerance
+        # fc1's forward split-K sums with fp32 atomics, and the conv split-K slabs are added in a different
+        # association order by the reduce launch (DP) and by the optimizer's folded sum (single rank), so
+        # the two runs differ in the last bits and Adam (g / |g|) amplifies that on near-zero gradients:
+        # compare with a tolerance
         for i in (0, 1):
             d = (flats[0][i] - flats[1][i]).abs()
-            assert d.max().item() <= 8 * 3e-4 and (d > 2e-5).float().mean().item() < 2e-2, \
+            assert d.max().item() <= 8 * 3e-4 and (d > 2e-5).float().mean().item() < 5e-2, \
                 (d.max().item(), (d > 2e-5).float().mean().item())
         assert abs(flats[0][2] - flats[1][2]) < 2e-2 * max(1.0, abs(flats[0][2]))
     finally:
