@@ -133,7 +133,9 @@ class DdpgTorchCore(_TorchCore):
                 p.requires_grad_(False)
         _, q_pi = self.model(s0)
         actor_loss = -q_pi.mean()
-        actor_loss.backward()
+        self._ddpg_updates = getattr(self, "_ddpg_updates", 0) + 1
+        if self._ddpg_updates >= int(getattr(self.ap, "actor_warmup_steps", 0)):    # critic warm-up: see options
+            actor_loss.backward()
         if not leak:
             for p in self.model.critic.parameters():
                 p.requires_grad_(True)

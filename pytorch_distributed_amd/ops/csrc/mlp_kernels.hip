@@ -44,6 +44,8 @@ PDA_EXPORT void pda_mlp_stage(const StageJobs* jobs, int njobs, const void* idx,
 // weight gradient, |td| leaves for the sum/min trees, the two loss sums.
 // With leak == 0 the actor-loss rows of dq are zero, so critic parameters only see the
 // critic loss (the reference lets the actor loss leak into them, ddpg_learner.py:66-86).
+// actor_warmup > 0 zeroes the actor-loss gradient for the first updates: the tanh policy is not pushed into
+// saturation by the gradient of a critic that has not seen any data yet (agent_params.actor_warmup_steps).
 // ----------------------------------------------------------------------------
 struct DdpgHeadArgs {
     const bf16_t* h2; long ldh;
@@ -54,6 +56,7 @@ struct DdpgHeadArgs {
     float* q_out; float* td_out; float* loss_sum;          // loss_sum[0] = actor, [1] = critic
     float* leaf_sum; float* leaf_min; float prio_eps, prio_alpha;
     int B, H, leak;
+    int actor_warmup;       // the actor loss is switched off while the update count is below this (critic warm-up)
     unsigned long long* rng_counter; int* opt_step;
 };
 
@@ -86,7 +89,10 @@ __global__ __launch_bounds__(256) void ddpg_head_kernel(DdpgHeadArgs p) {
     float w = p.isw ? p.isw[b] : 1.f;
     float invB = 1.f / (float)p.B;
     float dq_c = 2.f * w * td * invB;
-    float dq_pi = -invB;
+    // critic warm-up: no actor-loss gradient yet.  (The counter is bumped by workgroup 0 of this launch: at the
+    // one boundary step some samples may see either value, which is harmless.)
+    const bool actor_on = !(p.actor_warmup > 0 && p.opt_step && *p.opt_step < p.actor_warmup);
+    float dq_pi = actor_on ? -invB : 0.f;
 
     bf16_t* dp = p.dh2 + (long)b * p.ldh;
     bf16_t* dc = p.dh2 + (long)(p.B + b) * p.ldh;

@@ -72,7 +72,7 @@ class _DdpgHeadArgs(ctypes.Structure):      # mirrors DdpgHeadArgs in csrc/mlp_k
                 ("dh2", _vp), ("dq", _vp), ("dq_ld", ctypes.c_int),
                 ("q_out", _vp), ("td_out", _vp), ("loss_sum", _vp),
                 ("leaf_sum", _vp), ("leaf_min", _vp), ("prio_eps", ctypes.c_float), ("prio_alpha", ctypes.c_float),
-                ("B", ctypes.c_int), ("H", ctypes.c_int), ("leak", ctypes.c_int),
+                ("B", ctypes.c_int), ("H", ctypes.c_int), ("leak", ctypes.c_int), ("actor_warmup", ctypes.c_int),
                 ("rng_counter", _vp), ("opt_step", _vp)]
 
 
@@ -230,7 +230,8 @@ DDPG_LAYERS = ("actor.0", "actor.2", "actor.4", "critic.0.0", "critic.1.0", "cri
 
 class DdpgMlpEngine(_EngineBase):
     def __init__(self, model, target_model, batch_size, lr=1e-4, weight_decay=0.0, clip=40.0, tau=1e-3,
-                 per=None, seed=0, tail_offsets=(0, 1, 2, 3), leak=True):
+                 per=None, seed=0, tail_offsets=(0, 1, 2, 3), leak=True, actor_warmup=0):
+        self.actor_warmup = int(actor_warmup)
         self.online = MlpWeights(model, DDPG_LAYERS, with_grad=True, fp32_only=("critic.1.2",))
         self.target = MlpWeights(target_model, DDPG_LAYERS, with_grad=False, fp32_only=("critic.1.2",))
         on = self.online
@@ -310,7 +311,7 @@ class DdpgMlpEngine(_EngineBase):
             leaf_sum=_p(tree.sum) if tree is not None else 0, leaf_min=_p(tree.min) if tree is not None else 0,
             prio_eps=float(self.per["eps"]) if self.per else 0.0,
             prio_alpha=float(self.per["alpha"]) if self.per else 1.0,
-            B=B, H=self.C2, leak=1 if self.leak else 0,
+            B=B, H=self.C2, leak=1 if self.leak else 0, actor_warmup=self.actor_warmup,
             rng_counter=_p(self.counter), opt_step=_p(self.adam.step_dev))
         _L().pda_ddpg_head(ctypes.byref(args), _stream())
 
@@ -524,7 +525,8 @@ class MlpNativeCore(object):
         if kind == "ddpg":
             self.engine = DdpgMlpEngine(model, target_model, ap.batch_size, lr=ap.lr, weight_decay=ap.weight_decay,
                                         clip=ap.clip_grad, tau=ap.target_model_update, per=per, seed=seed,
-                                        tail_offsets=offs, leak=getattr(ap, "compat_ddpg_grad_leak", True))
+                                        tail_offsets=offs, leak=getattr(ap, "compat_ddpg_grad_leak", True),
+                                        actor_warmup=getattr(ap, "actor_warmup_steps", 0))
             assert self.engine.A == a
         else:
             self.engine = DqnMlpEngine(model, target_model, ap.batch_size, lr=ap.lr, weight_decay=ap.weight_decay,

@@ -41,7 +41,8 @@ PRESETS = {
     # DDPG: cap the replay ratio.  The reference's learner (~350 updates/s) never outruns its 8 actors; an
     # uncoupled 8k-updates/s learner makes thousands of updates per turnover of a 50k replay, the tanh actor
     # collapses to a constant saturated action and never recovers (measured: bench/learning_sanity.py,
-    # BASELINE.md).  0.005 updates per env step with the 50k replay, 0.02 with a 1M HBM replay both solve Pendulum.
+    # BASELINE.md).  0.005 updates per env step solves Pendulum with the 50k and with the 1M HBM replay; 0.02 did while
+    # the actors made ~40k env steps/s and stopped doing so once they got 3-4x faster (the cap is relative to them).
     3: {"num_actors": 8, "agent_params.nstep": 5, "agent_params.max_replay_ratio": 0.005},
     4: {"num_actors": 256, "actor_inference": "batched", "memory_params.memory_size": 2 * 1024 * 1024,
         "memory_params.enable_per": True, "agent_params.nstep": 5},
@@ -50,8 +51,13 @@ PRESETS = {
     6: {"num_actors": 2, "agent_params.nstep": 3, "agent_params.learn_start": 200,
         "agent_params.batch_size": 32, "agent_params.target_model_update": 50,
         "agent_params.lr": 1e-3, "memory_params.memory_size": 5000},
-    7: {"num_actors": 8, "agent_params.nstep": 5, "agent_params.max_replay_ratio": 0.02,
-        "memory_params.memory_size": 1024 * 1024, "agent_params.learn_start": 20000},
+    # 7 = the DDPG recipe that solves Pendulum here (bench/learning_sanity.py): besides the ratio cap, lr 1e-3 and
+    # the critic NOT updated by the actor loss (row 3 keeps the reference's defaults: lr 1e-4 and that leak, with
+    # which neither the fp32 torch core nor the native one leaves the saturated-action plateau in 100 k steps)
+    7: {"num_actors": 8, "agent_params.nstep": 5, "agent_params.max_replay_ratio": 0.005,
+        "memory_params.memory_size": 1024 * 1024, "agent_params.learn_start": 20000,
+        "agent_params.lr": 1e-3, "agent_params.compat_ddpg_grad_leak": False,
+        "agent_params.actor_warmup_steps": 2000},
 }
 
 
@@ -241,6 +247,7 @@ class AgentParams(Params):
             # the reference lets the actor loss deposit gradients into the critic
             # (ddpg_learner.py:66-86); False freezes the critic during the actor loss
             self.compat_ddpg_grad_leak = True
+            self.actor_warmup_steps = 0      # DDPG: learner updates during which only the critic is trained (0: as the reference)
 
 
 _NESTED = ("env_params", "memory_params", "model_params", "agent_params")

@@ -231,6 +231,35 @@ def test_ddpg_dp_equivalence_fake_comm():
         assert _same_params(core.model.flat_params, single.model.flat_params)
 
 
+def test_ddpg_actor_warmup_trains_only_the_critic():
+    """agent_params.actor_warmup_steps: during the warm-up the actor loss is not applied (the actor keeps its
+    initial weights, the critic trains); afterwards both move."""
+    B = 8
+    opt = prepare_options(Options(config=3, overrides={"device": "cpu", "agent_params.batch_size": B,
+                                                       "agent_params.lr": 1e-3, "agent_params.actor_warmup_steps": 3,
+                                                       "agent_params.compat_ddpg_grad_leak": False}))
+    D, A = int(np.prod(opt.state_shape)), int(opt.action_shape)
+    g = torch.Generator().manual_seed(5)
+    full = [(torch.randn(B, 1, D, generator=g), torch.rand(B, A, generator=g) * 2 - 1, torch.randn(B, 1, generator=g),
+             torch.full((B, 1), 0.95), torch.randn(B, 1, D, generator=g), torch.zeros(B, 1))]
+    torch.manual_seed(1)
+    proto = ModelsDict[opt.model_type](opt.model_params, opt.norm_val, opt.state_shape, opt.action_space,
+                                       opt.action_shape)
+    core = DdpgTorchCore(opt, copy.deepcopy(proto), copy.deepcopy(proto), FixedBatchMemory(full), SingleComm())
+    actor0 = torch.cat([p.detach().reshape(-1).clone() for p in core.model.actor.parameters()])
+    critic0 = torch.cat([p.detach().reshape(-1).clone() for p in core.model.critic.parameters()])
+    for _ in range(2):
+        core.step()
+    actor1 = torch.cat([p.detach().reshape(-1) for p in core.model.actor.parameters()])
+    critic1 = torch.cat([p.detach().reshape(-1) for p in core.model.critic.parameters()])
+    assert torch.equal(actor0, actor1)
+    assert (critic0 - critic1).abs().max().item() > 0
+    for _ in range(3):
+        core.step()
+    actor2 = torch.cat([p.detach().reshape(-1) for p in core.model.actor.parameters()])
+    assert (actor0 - actor2).abs().max().item() > 0
+
+
 def _weight_sync_worker(rank, port, out_q):
     """2 learner ranks + 1 inference rank in one gloo world: sub-group collectives + weight broadcast."""
     from pytorch_distributed_amd.parallel.weight_sync import WeightPublisher, WeightReceiver

@@ -139,6 +139,29 @@ def test_ddpg_steps_track_torch_core(eng):
     assert w[:, e.CK:].abs().max().item() == 0.0
 
 
+def test_ddpg_actor_warmup_native(eng):
+    """actor_warmup: the head kernel switches the actor loss off while the update count is below it."""
+    B, D, A = 64, 3, 1
+    model, target = make_ddpg(D, A)
+    e = eng.DdpgMlpEngine(model, target, B, lr=1e-3, clip=40.0, tau=0.05, tail_offsets=(0, A, A + 1, A + 2),
+                          leak=False, actor_warmup=3)
+    s0, s1, tails = ddpg_batch(B, D, A)
+    e.make_staging(A + 4)
+    e.stage_s0.copy_(s0); e.stage_s1.copy_(s1); e.stage_tails.copy_(tails)
+    prog = eng.MlpStepProgram(e, None, use_graph=True, staged=True)
+    n_actor = sum(p.numel() for p in model.actor.parameters())
+    flat0 = e.online.flat.clone()
+    for _ in range(2):
+        prog.step()
+    torch.cuda.synchronize()
+    assert torch.equal(e.online.flat[:n_actor], flat0[:n_actor])
+    assert (e.online.flat[n_actor:] - flat0[n_actor:]).abs().max().item() > 0
+    for _ in range(3):
+        prog.step()
+    torch.cuda.synchronize()
+    assert (e.online.flat[:n_actor] - flat0[:n_actor]).abs().max().item() > 0
+
+
 def test_ddpg_overfits_and_per_device_replay(eng):
     from pytorch_distributed_amd.memories.device_memory import DeviceMemory
     from pytorch_distributed_amd.utils.options import Options
