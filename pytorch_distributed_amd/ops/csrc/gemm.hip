@@ -189,6 +189,28 @@ PDA_EXPORT void pda_conv_wgrad(const void* dy, const void* x, void* gw, void* gb
     else launch_gemm<64, 64, 2, 2>(a, 1, O, K, M, ksplit, stream);
 }
 
+// Two conv weight gradients (same output-channel count) as problem groups of ONE launch with a common
+// split-K slice length: at batch 128 each of conv2 / conv3 alone is ~240 workgroups, less than one per CU,
+// and the two launches ran back to back (2 x 9 us); together they fill the chip once.
+PDA_EXPORT void pda_conv_wgrad_pair(const void* const* dy, const void* const* x, void* const* gw, void* const* gb,
+                                    int batch, const int* H, const int* W, const int* C, const int* KH,
+                                    const int* KW, const int* S, int O, const long* slice_stride,
+                                    const long* bslice_stride, int ksplit, hipStream_t stream) {
+    GemmArgs<SrcDenseT, SrcIm2colT, EpiWgrad> a;
+    int maxN = 0, maxK = 0;
+    for (int i = 0; i < 2; ++i) {
+        ConvGeom g = make_geom(H[i], W[i], C[i], KH[i], KW[i], S[i]);
+        int M = batch * g.OH * g.OW, K = C[i] * KH[i] * KW[i];
+        a.g[i].a = {(const bf16_t*)dy[i], (long)O, O, M};
+        a.g[i].b = {(const bf16_t*)x[i], g, K, M};
+        a.g[i].e = {(float*)gw[i], (float*)gb[i], (long)K, slice_stride[i], bslice_stride[i], 1.f};
+        a.g[i].M = O; a.g[i].N = K; a.g[i].K = M;
+        if (K > maxN) maxN = K;
+        if (M > maxK) maxK = M;
+    }
+    launch_gemm<64, 64, 2, 2>(a, 2, O, maxN, maxK, ksplit, stream);
+}
+
 // conv1 from uint8 frames: gw[O][(c,ky,kx)] (== PyTorch's own order)
 PDA_EXPORT void pda_conv_wgrad_u8(const void* dy, const void* frames, const void* idx, void* gw, void* gb,
                                   int batch, int H, int W, int C, int KH, int KW, int S, int O, float scale,

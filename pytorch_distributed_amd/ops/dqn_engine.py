@@ -228,6 +228,7 @@ class _Acts(object):
 
 
 _WGRAD_BLOCKS = int(os.environ.get("PDA_WGRAD_BLOCKS", "256"))  # split-K target for the conv weight gradients
+_PAIR_BLOCKS = int(os.environ.get("PDA_PAIR_BLOCKS", "512"))    # same, for the conv2 + conv3 launch as a whole
 _FC1_BLOCKS = int(os.environ.get("PDA_FC1_BLOCKS", "256"))     # split-K target for fc1 forward (blocks per launch)
 
 
@@ -274,6 +275,7 @@ class DqnCnnEngine(object):
                              clip=clip, shadow=self.online.shadow)
         self.groups = 3 if self.double else 2
         self.acts = _Acts(g, self.B, self.groups, dev, backward=True)
+        self.pair_wgrad = bool(self.acts.stack_dgrad) and os.environ.get("PDA_PAIR_WGRAD", "1") != "0"
         self._plan_wgrads()
         self._fc_pair = None
         self.idx = torch.zeros(self.B, dtype=torch.int32, device=dev)
@@ -308,6 +310,11 @@ class DqnCnnEngine(object):
                                           (64, g.K3, B * g.P3)]):
             tiles = ((O + 63) // 64 if O > 32 else 1) * ((K + 63) // 64)
             ks = _ksplit(red, tiles, _WGRAD_BLOCKS, 128)
+            if li > 0 and self.pair_wgrad:
+                # conv2 + conv3 go out as two problem groups of one launch with a common slice length, sized so
+                # that the launch as a whole is ~_PAIR_BLOCKS workgroups
+                work = 8 * (B * g.H2 * g.W2) + 9 * (B * g.P3)
+                ks = nn.round_ksplit(max(128, (work + _PAIR_BLOCKS - 1) // _PAIR_BLOCKS))
             ns = nn.num_slices(red, ks)
             if li == 0 and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32):
                 ns = nn.conv1_wgrad_slices(B)       # whole-image kernel: one slice per workgroup
@@ -434,10 +441,16 @@ class DqnCnnEngine(object):
         if a.stack_dgrad:
             # both conv data gradients in one launch (per-image, LDS-resident), then the two weight gradients
             nn.cnn_dgrad_stack(a.da3, a.a2[0], a.a1[0], on.w[2], on.w[1], a.da2, a.da1, B)
-            nn.conv_wgrad(a.da3, a.a2[0], w3s, b3s, B, g.H2, g.W2, 64, 3, 3, 1, 64, ksplit=ks3, slice_stride=st3,
-                          bslice_stride=bst3)
-            nn.conv_wgrad(a.da2, a.a1[0], w2s, b2s, B, g.H1, g.W1, 32, 4, 4, 2, 64, ksplit=ks2, slice_stride=st2,
-                          bslice_stride=bst2)
+            if self.pair_wgrad:
+                assert ks2 == ks3
+                nn.conv_wgrad_pair([a.da2, a.da3], [a.a1[0], a.a2[0]], [w2s, w3s], [b2s, b3s], B,
+                                   [(g.H1, g.W1, 32, 4, 4, 2), (g.H2, g.W2, 64, 3, 3, 1)], 64, ks2,
+                                   [st2, st3], [bst2, bst3])
+            else:
+                nn.conv_wgrad(a.da3, a.a2[0], w3s, b3s, B, g.H2, g.W2, 64, 3, 3, 1, 64, ksplit=ks3, slice_stride=st3,
+                              bslice_stride=bst3)
+                nn.conv_wgrad(a.da2, a.a1[0], w2s, b2s, B, g.H1, g.W1, 32, 4, 4, 2, 64, ksplit=ks2, slice_stride=st2,
+                              bslice_stride=bst2)
         else:
             self._backward_conv_layerwise(a, on, B, M3, M2, on_side, (w3s, b3s, ks3, st3, bst3),
                                           (w2s, b2s, ks2, st2, bst2))

@@ -222,6 +222,23 @@ def conv_wgrad(dy, x, gw, gb, batch, H, W, C, KH, KW, S, O, ksplit=0, slice_stri
                         slice_stride, bslice_stride, ksplit, _stream())
 
 
+def conv_wgrad_pair(dys, xs, gws, gbs, batch, geoms, O, ksplit, slice_strides, bslice_strides):
+    """Two conv weight gradients in one launch (csrc/gemm.hip:pda_conv_wgrad_pair).
+    geoms: [(H, W, C, KH, KW, S)] x 2; both problems use the split-K slice length `ksplit`."""
+    import ctypes as _ct
+    L = _L()
+    if not getattr(L, "_pair_ready", False):
+        L.pda_conv_wgrad_pair.argtypes = [_vp] * 4 + [_ct.c_int] + [_vp] * 6 + [_ct.c_int, _vp, _vp, _ct.c_int, _vp]
+        L.pda_conv_wgrad_pair.restype = None
+        L._pair_ready = True
+    cols = list(zip(*geoms))
+    iarr = [(_ct.c_int * 2)(*[int(v) for v in col]) for col in cols]
+    ss = (_ct.c_long * 2)(*[int(v) for v in slice_strides])
+    bs = (_ct.c_long * 2)(*[int(v) for v in bslice_strides])
+    L.pda_conv_wgrad_pair(_arr(dys), _arr(xs), _arr(gws), _arr(gbs), int(batch), iarr[0], iarr[1], iarr[2], iarr[3],
+                          iarr[4], iarr[5], int(O), ss, bs, int(ksplit), _stream())
+
+
 def conv_wgrad_u8(dy, frames, idx, gw, gb, batch, H, W, C, KH, KW, S, O, scale, ksplit=0, slice_stride=0,
                   bslice_stride=0):
     assert ksplit == 0 or slice_stride >= O * C * KH * KW
