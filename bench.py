@@ -175,6 +175,7 @@ def main():
                        "collectives": (getattr(comm, "backend", None) if getattr(getattr(core, "program", None), "dp", False)
                                        else None),
                        "dp_graph": getattr(getattr(core, "program", None), "dp_graph_mode", None),
+                       "dp_grad_allreduce_dtype": getattr(getattr(core, "program", None), "grad_dtype", None),
                        "hip_graph": bool(native and not a.no_graph)},
         }
         out.update(extra)
