@@ -171,6 +171,31 @@ def test_conv_backward_nhwc(nn, geom):
     close(nn.from_nhwc(dx2, batch, H, W, C), x.grad * (x.detach() > 0), 3e-2, 3e-2)
 
 
+def test_conv_wgrad_pair_equals_separate_launches(nn):
+    """conv2 + conv3 weight gradients as two problem groups of one launch (common split-K slice length)
+    write the same slabs, bit for bit, as the two separate launches."""
+    torch.manual_seed(12)
+    batch, ks = 24, 256
+    geoms = [(20, 20, 32, 4, 4, 2), (9, 9, 64, 3, 3, 1)]
+    dys, xs, sep, pair = [], [], [], []
+    for (H, W, C, KH, KW, S) in geoms:
+        OH, OW = nn.conv_out(H, KH, S), nn.conv_out(W, KW, S)
+        K = C * KH * KW
+        ns = nn.num_slices(batch * OH * OW, ks)
+        dys.append(bf(torch.randn(batch * OH * OW, 64, device="cuda")).bfloat16())
+        xs.append(bf(torch.relu(torch.randn(batch * H * W, C, device="cuda"))).bfloat16())
+        sep.append((torch.full((ns, 64 * K), 7.0, device="cuda"), torch.full((ns, 64), 7.0, device="cuda"), K))
+        pair.append((torch.full((ns, 64 * K), 9.0, device="cuda"), torch.full((ns, 64), 9.0, device="cuda"), K))
+    for (H, W, C, KH, KW, S), dy, x, (slab, bslab, K) in zip(geoms, dys, xs, sep):
+        nn.conv_wgrad(dy, x, slab, bslab, batch, H, W, C, KH, KW, S, 64, ksplit=ks, slice_stride=64 * K,
+                      bslice_stride=64)
+    nn.conv_wgrad_pair(dys, xs, [p[0] for p in pair], [p[1] for p in pair], batch, geoms, 64, ks,
+                       [64 * p[2] for p in pair], [64, 64])
+    torch.cuda.synchronize()
+    for (s, bs, _), (p, bp, _) in zip(sep, pair):
+        assert torch.equal(s, p) and torch.equal(bs, bp)
+
+
 @pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("batch", [8, 300])
 def test_conv1_wgrad_u8(nn, batch, generic, monkeypatch):
