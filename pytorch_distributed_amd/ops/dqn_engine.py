@@ -228,6 +228,9 @@ class _Acts(object):
 
 
 _WGRAD_BLOCKS = int(os.environ.get("PDA_WGRAD_BLOCKS", "256"))  # split-K target for the conv weight gradients
+# batch from which the per-image conv2+conv3 wgrad kernel is used: at 4096 it is worth +5.8 % (1224 -> 1295 updates/s;
+# the kernel itself 197 -> 101 us, but the optimizer then sums 256 slab slices); at 1024 it loses (3528 -> 3247)
+_WGRAD_STACK_MIN = int(os.environ.get("PDA_WGRAD_STACK_MIN", "4096"))
 _PAIR_BLOCKS = int(os.environ.get("PDA_PAIR_BLOCKS", "512"))    # same, for the conv2 + conv3 launch as a whole
 _FC1_BLOCKS = int(os.environ.get("PDA_FC1_BLOCKS", "256"))     # split-K target for fc1 forward (blocks per launch)
 
@@ -276,6 +279,8 @@ class DqnCnnEngine(object):
         self.groups = 3 if self.double else 2
         self.acts = _Acts(g, self.B, self.groups, dev, backward=True)
         self.pair_wgrad = bool(self.acts.stack_dgrad) and os.environ.get("PDA_PAIR_WGRAD", "1") != "0"
+        # large batches: conv2 + conv3 weight gradients per image with register accumulation (csrc/conv1_kernels.hip)
+        self.stack_wgrad = bool(self.acts.stack_dgrad) and self.B >= _WGRAD_STACK_MIN
         self._plan_wgrads()
         self._fc_pair = None
         self.idx = torch.zeros(self.B, dtype=torch.int32, device=dev)
@@ -310,12 +315,14 @@ class DqnCnnEngine(object):
                                           (64, g.K3, B * g.P3)]):
             tiles = ((O + 63) // 64 if O > 32 else 1) * ((K + 63) // 64)
             ks = _ksplit(red, tiles, _WGRAD_BLOCKS, 128)
-            if li > 0 and self.pair_wgrad:
+            if li > 0 and self.stack_wgrad:
+                ks, ns_override = 0, nn.cnn_wgrad_stack_slices(B)      # per-image kernel: one slice per workgroup
+            elif li > 0 and self.pair_wgrad:
                 # conv2 + conv3 go out as two problem groups of one launch with a common slice length, sized so
                 # that the launch as a whole is ~_PAIR_BLOCKS workgroups
                 work = 8 * (B * g.H2 * g.W2) + 9 * (B * g.P3)
                 ks = nn.round_ksplit(max(128, (work + _PAIR_BLOCKS - 1) // _PAIR_BLOCKS))
-            ns = nn.num_slices(red, ks)
+            ns = nn.num_slices(red, ks) if ks > 0 else ns_override
             if li == 0 and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32):
                 ns = nn.conv1_wgrad_slices(B)       # whole-image kernel: one slice per workgroup
             plans.append((li, O, K, ks, ns))
@@ -441,7 +448,9 @@ class DqnCnnEngine(object):
         if a.stack_dgrad:
             # both conv data gradients in one launch (per-image, LDS-resident), then the two weight gradients
             nn.cnn_dgrad_stack(a.da3, a.a2[0], a.a1[0], on.w[2], on.w[1], a.da2, a.da1, B)
-            if self.pair_wgrad:
+            if self.stack_wgrad:
+                nn.cnn_wgrad_stack(a.a1[0], a.a2[0], a.da2, a.da3, w2s, b2s, w3s, b3s, B)
+            elif self.pair_wgrad:
                 assert ks2 == ks3
                 nn.conv_wgrad_pair([a.da2, a.da3], [a.a1[0], a.a2[0]], [w2s, w3s], [b2s, b3s], B,
                                    [(g.H1, g.W1, 32, 4, 4, 2), (g.H2, g.W2, 64, 3, 3, 1)], 64, ks2,

@@ -118,6 +118,25 @@ def cnn_dgrad_stack(da3, a2, a1, w3, w2, da2, da1, batch):
                              _stream())
 
 
+def cnn_wgrad_stack_slices(batch):
+    L = _L()
+    L.pda_cnn_wgrad_stack_slices.argtypes = [ctypes.c_int]
+    L.pda_cnn_wgrad_stack_slices.restype = ctypes.c_int
+    return int(L.pda_cnn_wgrad_stack_slices(int(batch)))
+
+
+def cnn_wgrad_stack(a1, a2, da2, da3, gw2, gb2, gw3, gb3, batch):
+    """conv2 + conv3 weight gradients of the Nature CNN (84x84 inputs) per image, accumulated in registers over a
+    workgroup's images: slab slices [cnn_wgrad_stack_slices(batch)][64*512], [..][64], [..][64*576], [..][64]."""
+    L = _L()
+    if not getattr(L, "_wgstack_ready", False):
+        L.pda_cnn_wgrad_stack.argtypes = [_vp] * 8 + [ctypes.c_long] * 4 + [ctypes.c_int, _vp]
+        L.pda_cnn_wgrad_stack.restype = None
+        L._wgstack_ready = True
+    L.pda_cnn_wgrad_stack(_ptr(a1), _ptr(a2), _ptr(da2), _ptr(da3), _ptr(gw2), _ptr(gb2), _ptr(gw3), _ptr(gb3),
+                          64 * 512, 64, 64 * 576, 64, int(batch), _stream())
+
+
 def conv1_wgrad_slices(batch):
     return int(_L().pda_conv1_wgrad_slices(int(batch)))
 

@@ -196,6 +196,36 @@ def test_conv_wgrad_pair_equals_separate_launches(nn):
         assert torch.equal(s, p) and torch.equal(bs, bp)
 
 
+@pytest.mark.parametrize("batch", [3, 300])
+def test_cnn_wgrad_stack_matches_torch(nn, batch):
+    """conv2 + conv3 weight / bias gradients per image with register accumulation == fp32 torch conv backward
+    (300 images > 256 workgroups exercises the per-workgroup image loop and its prefetch)."""
+    torch.manual_seed(13)
+    a1 = bf(torch.relu(torch.randn(batch, 32, 20, 20, device="cuda"))).requires_grad_(True)
+    a2 = bf(torch.relu(torch.randn(batch, 64, 9, 9, device="cuda"))).requires_grad_(True)
+    w2 = torch.zeros(64, 32, 4, 4, device="cuda", requires_grad=True)
+    w3 = torch.zeros(64, 64, 3, 3, device="cuda", requires_grad=True)
+    b2 = torch.zeros(64, device="cuda", requires_grad=True)
+    b3 = torch.zeros(64, device="cuda", requires_grad=True)
+    da2 = bf(torch.randn(batch, 64, 9, 9, device="cuda"))
+    da3 = bf(torch.randn(batch, 64, 7, 7, device="cuda"))
+    F.conv2d(a1, w2, b2, stride=2).backward(da2)
+    F.conv2d(a2, w3, b3, stride=1).backward(da3)
+    ns = nn.cnn_wgrad_stack_slices(batch)
+    s2, sb2 = torch.full((ns, 64 * 512), 7.0, device="cuda"), torch.full((ns, 64), 7.0, device="cuda")
+    s3, sb3 = torch.full((ns, 64 * 576), 7.0, device="cuda"), torch.full((ns, 64), 7.0, device="cuda")
+    nn.cnn_wgrad_stack(nn.nhwc(a1.detach()), nn.nhwc(a2.detach()), nn.nhwc(da2), nn.nhwc(da3), s2, sb2, s3, sb3, batch)
+    gw2, gb2 = torch.zeros(64, 4, 4, 32, device="cuda"), torch.zeros(64, device="cuda")
+    gw3, gb3 = torch.zeros(64, 3, 3, 64, device="cuda"), torch.zeros(64, device="cuda")
+    nn.ReducePlan([(s2, gw2, 64 * 512, ns, 64 * 512), (sb2, gb2, 64, ns, 64),
+                   (s3, gw3, 64 * 576, ns, 64 * 576), (sb3, gb3, 64, ns, 64)]).run()
+    tol = 3e-3 * max(1.0, batch / 8) ** 0.5
+    close(gw2.permute(0, 3, 1, 2), w2.grad, tol, 3e-3)
+    close(gw3.permute(0, 3, 1, 2), w3.grad, tol, 3e-3)
+    close(gb2, b2.grad, tol, 3e-3)
+    close(gb3, b3.grad, tol, 3e-3)
+
+
 @pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("batch", [8, 300])
 def test_conv1_wgrad_u8(nn, batch, generic, monkeypatch):

@@ -32,7 +32,7 @@ def timeit(fn, n=20, reps=20):
     return e0.elapsed_time(e1) / (n * reps) * 1e3
 
 
-for B in (1, 128, 256, 1024, 4096):
+for B in (1, 128, 256, 512, 1024, 4096):
     idx = torch.randint(0, 4096, (B,), dtype=torch.int32, device=dev)
     a1 = torch.zeros(B * 400, 32, dtype=bf, device=dev); a2 = torch.zeros(B * 81, 64, dtype=bf, device=dev)
     a3 = torch.zeros(B * 49, 64, dtype=bf, device=dev)
@@ -45,8 +45,19 @@ for B in (1, 128, 256, 1024, 4096):
     f3 = lambda: nn.cnn_dgrad_stack(da3, a2, a1, w3, w2, da2, da1, B)
     f4 = lambda: nn.conv_wgrad_u8(da1, mem, idx, slab, bslab, B, 84, 84, 4, 8, 8, 4, 32, 1 / 255., ksplit=0,
                                   slice_stride=32 * 256, bslice_stride=32)
-    print("B=%5d  fwd(1 group) %7.1f us  fwd(2 groups) %7.1f us  dgrad stack %7.1f us  conv1 wgrad %7.1f us"
-          % (B, timeit(f1), timeit(f2), timeit(f3), timeit(f4)), flush=True)
+    ns = nn.cnn_wgrad_stack_slices(B)
+    s2, sb2 = torch.zeros(ns, 64 * 512, device=dev), torch.zeros(ns, 64, device=dev)
+    s3, sb3 = torch.zeros(ns, 64 * 576, device=dev), torch.zeros(ns, 64, device=dev)
+    f5 = lambda: nn.cnn_wgrad_stack(a1, a2, da2, da3, s2, sb2, s3, sb3, B)
+    ks = nn.round_ksplit(max(128, (8 * B * 81 + 9 * B * 49 + 511) // 512))
+    n2, n3 = nn.num_slices(B * 81, ks), nn.num_slices(B * 49, ks)
+    p2, pb2 = torch.zeros(n2, 64 * 512, device=dev), torch.zeros(n2, 64, device=dev)
+    p3, pb3 = torch.zeros(n3, 64 * 576, device=dev), torch.zeros(n3, 64, device=dev)
+    f6 = lambda: nn.conv_wgrad_pair([da2, da3], [a1, a2], [p2, p3], [pb2, pb3], B,
+                                    [(20, 20, 32, 4, 4, 2), (9, 9, 64, 3, 3, 1)], 64, ks, [64 * 512, 64 * 576], [64, 64])
+    print("B=%5d  fwd(1 group) %7.1f us  fwd(2 groups) %7.1f us  dgrad stack %7.1f us  conv1 wgrad %7.1f us  "
+          "conv2+3 wgrad: per-image %7.1f us (%d slices), GEMM pair %7.1f us (%d + %d slices)"
+          % (B, timeit(f1), timeit(f2), timeit(f3), timeit(f4), timeit(f5), ns, timeit(f6), n2, n3), flush=True)
 
 
 # ---- phase stamps of workgroup (0, 0) (shader clock cycles), forward stack
