@@ -48,6 +48,8 @@ def main():
                     help="run the data-parallel step program even with one rank (rehearsal of the collective path)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="all ranks on cuda:0 (gloo rehearsal of the multi-rank program on a one-GPU box)")
+    ap.add_argument("--graph-steps", type=int, default=None,
+                    help="learner updates per hipGraph replay (default: the option's, 5; 1 = one graph per step)")
     ap.add_argument("--actor-bench", action="store_true", help="also time batched actor inference (untimed extra)")
     a = ap.parse_args()
 
@@ -78,6 +80,8 @@ def main():
         "device": "cuda", "compute": a.compute, "num_learners": world, "force_dp": a.force_dp,
         "memory_params.memory_size": a.replay * world,      # each rank keeps a `replay`-sized shard
         "agent_params.batch_size": a.batch}))
+    if a.graph_steps is not None:
+        opt.graph_steps = int(a.graph_steps)
     ap_ = opt.agent_params
     torch.manual_seed(opt.seed)
 
@@ -176,7 +180,8 @@ def main():
                                        else None),
                        "dp_graph": getattr(getattr(core, "program", None), "dp_graph_mode", None),
                        "dp_grad_allreduce_dtype": getattr(getattr(core, "program", None), "grad_dtype", None),
-                       "hip_graph": bool(native and not a.no_graph)},
+                       "hip_graph": bool(native and not a.no_graph),
+                       "steps_per_graph": getattr(getattr(core, "program", None), "graph_steps", None)},
         }
         out.update(extra)
         print(json.dumps(out), flush=True)

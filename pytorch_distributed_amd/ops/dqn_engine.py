@@ -533,7 +533,7 @@ class DqnStepProgram(object):
 
     The all-reduce is a SUM; the 1/world_size is Adam's grad_scale, so no scaling launch exists."""
 
-    def __init__(self, engine, comm=None, use_graph=True, staged=False, force_dp=False):
+    def __init__(self, engine, comm=None, use_graph=True, staged=False, force_dp=False, graph_steps=1):
         self.e, self.comm, self.staged = engine, comm, staged
         self.world = comm.world_size if comm is not None else 1
         self.dp = comm is not None and (self.world > 1 or force_dp)
@@ -541,6 +541,19 @@ class DqnStepProgram(object):
         self.graphs = None
         self.dp_graph_mode = None
         self.calls = 0
+        # Updates per graph replay.  Between two replays the GPU idles ~8 us (graph completion + next launch: the
+        # kernels inside a graph run back to back, tools/step_gaps.py), 9 % of a 0.09 ms step; a graph of K steps
+        # pays it once per K.  The program then runs AHEAD of its caller: the first step() of a group performs K
+        # updates, the next K - 1 calls return at once.  Only for the single-rank, HBM-replay program, and K is cut
+        # down to a divisor of the hard target-update period so that those updates still fall between replays.
+        k = int(os.environ.get("PDA_GRAPH_STEPS", graph_steps) or 1)
+        if self.dp or staged or not use_graph:
+            k = 1
+        tu = engine.target_update
+        if k > 1 and tu >= 1.0:
+            while k > 1 and int(tu) % k != 0:
+                k -= 1
+        self.graph_steps, self.ahead = max(1, k), 0
         self.fused_tail = (not self.dp) and os.environ.get("PDA_FUSED_TAIL", "1") != "0"
         self.presampled = False
         self.extras = engine.fused_extras(staged) if self.fused_tail else None
@@ -683,7 +696,12 @@ class DqnStepProgram(object):
 
     def step(self):
         e = self.e
+        if self.ahead > 0:              # this update already ran as part of the last multi-step replay
+            self.ahead -= 1
+            self.calls += 1
+            return
         first = (not self.use_graph) or self.calls == 0
+        done = 1
         # the first step runs eagerly: it loads every code object (and lets RCCL set up its
         # channels), so nothing is lazily initialised while a stream is capturing
         if not self.dp:
@@ -691,8 +709,13 @@ class DqnStepProgram(object):
                 self._whole()
             else:
                 if self.graphs is None:
-                    self.graphs = self._capture([self._whole])
+                    def k_steps():
+                        for _ in range(self.graph_steps):
+                            self._whole()
+                    self.graphs = self._capture([k_steps])
                 self.graphs[0].replay()
+                done = self.graph_steps
+                self.ahead = done - 1
         else:
             if first:
                 self._dp_whole()
@@ -704,7 +727,10 @@ class DqnStepProgram(object):
                 else:
                     self._run_dp(self.graphs[0].replay, self.graphs[1].replay)
         self.calls += 1
-        e.loss_steps += 1
+        e.loss_steps += done
+        # (with K updates per replay the period is a multiple of K and the first step ran alone, so a due
+        # update is always the last one of the replay)
+        e.step_count += done - 1
         if e.target_update >= 1.0 and e.step_count % int(e.target_update) == 0:
             e.hard_target_update()
         e.step_count += 1
@@ -732,7 +758,8 @@ class DqnNativeCore(object):
         else:
             self.engine.make_staging(a + 3 * k + 1)
         self.program = DqnStepProgram(self.engine, comm, use_graph=use_graph, staged=not self.on_device,
-                                      force_dp=force_dp or bool(getattr(args, "force_dp", False)))
+                                      force_dp=force_dp or bool(getattr(args, "force_dp", False)),
+                                      graph_steps=int(getattr(args, "graph_steps", 1)))
         self._last_size = -1
         self.step_count = 0
 

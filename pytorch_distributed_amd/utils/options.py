@@ -134,6 +134,8 @@ class Params(object):
         self.inject_fault = None            # e.g. "actor:1@50" kills actor 1 at its 50th step (tests)
         self.ingest = "ring"                # "ring": lock-free shm ring into device replay | "direct"
         self.force_dp = False               # run the data-parallel step program even with one learner (rehearsal)
+        self.graph_steps = 5                # native DQN learner, HBM replay, one rank: updates per hipGraph replay (the
+                                            # learner runs up to graph_steps - 1 updates ahead of its step counter)
 
         # prefix for saving models&logs
         self.root_dir = overrides.get("root_dir", os.getcwd())

@@ -225,6 +225,37 @@ def test_device_replay_uniform_and_per_steps(eng):
             assert abs(tree.min_value().item() - tree.min[:4096].min().item()) < 1e-6
 
 
+def test_multi_step_graph_runs_ahead_and_keeps_target_updates_aligned(eng):
+    """graph_steps > 1: one replay performs K updates (K cut down to a divisor of the target-update period), the
+    following K - 1 step() calls return at once, and the hard target update still lands on its period."""
+    B = 32
+    s0, s1, tails = make_batch(B, 6)
+    model, target = make_models(seed=3)
+    e = eng.DqnCnnEngine(model, target, B, lr=3e-4, target_update=6, seed=5)
+    mem_n = 256
+    g = torch.Generator(device="cuda").manual_seed(1)
+    frames = torch.randint(0, 256, (mem_n, 4, 84, 84), dtype=torch.uint8, device="cuda", generator=g)
+    rt = torch.zeros(mem_n, tails.shape[1], device="cuda")
+    rt[:, :] = tails[0]
+    e.bind_replay(frames, frames.flip(0).contiguous(), rt, None)
+    e.set_size(mem_n)
+    prog = eng.DqnStepProgram(e, None, use_graph=True, staged=False, graph_steps=4)
+    assert prog.graph_steps == 3            # 6 % 4 != 0 -> 3
+    prog.step()                             # eager, update 0 (+ target update)
+    assert e.step_count == 1 and prog.ahead == 0
+    prog.step()                             # captures and replays updates 1..3
+    assert e.step_count == 4 and prog.ahead == 2
+    before = e.online.flat.clone()
+    prog.step(); prog.step()                # already done
+    torch.cuda.synchronize()
+    assert torch.equal(before, e.online.flat) and prog.ahead == 0
+    prog.step()                             # updates 4..6: the last one is due for the hard target update
+    torch.cuda.synchronize()
+    assert e.step_count == 7
+    assert torch.equal(e.target.flat, e.online.flat)
+    assert np.isfinite(e.mean_loss())
+
+
 def test_batched_inference_matches_model(eng):
     model, _ = make_models()
     model.eval()
