@@ -544,10 +544,11 @@ class DqnStepProgram(object):
         # Updates per graph replay.  Between two replays the GPU idles ~8 us (graph completion + next launch: the
         # kernels inside a graph run back to back, tools/step_gaps.py), 9 % of a 0.09 ms step; a graph of K steps
         # pays it once per K.  The program then runs AHEAD of its caller: the first step() of a group performs K
-        # updates, the next K - 1 calls return at once.  Only for the single-rank, HBM-replay program, and K is cut
+        # updates, the next K - 1 calls return at once.  Only for the HBM-replay programs (single rank, or data
+        # parallel with the collectives captured in the graph), and K is cut
         # down to a divisor of the hard target-update period so that those updates still fall between replays.
         k = int(os.environ.get("PDA_GRAPH_STEPS", graph_steps) or 1)
-        if self.dp or staged or not use_graph:
+        if staged or not use_graph:
             k = 1
         tu = engine.target_update
         if k > 1 and tu >= 1.0:
@@ -690,8 +691,13 @@ class DqnStepProgram(object):
         whole = self.comm.all_agree(mode == "whole")
         if whole:
             self.dp_graph_mode = "whole"
-            return self._capture([self._dp_whole])
+
+            def k_steps():
+                for _ in range(self.graph_steps):
+                    self._dp_whole()
+            return self._capture([k_steps])
         self.dp_graph_mode = "split"
+        self.graph_steps = 1            # collectives stay host-driven: one step per pair of graphs
         return self._capture([self._part_a, self._part_b])
 
     def step(self):
@@ -724,6 +730,8 @@ class DqnStepProgram(object):
                     self.graphs = self._capture_dp()
                 if len(self.graphs) == 1:
                     self.graphs[0].replay()
+                    done = self.graph_steps
+                    self.ahead = done - 1
                 else:
                     self._run_dp(self.graphs[0].replay, self.graphs[1].replay)
         self.calls += 1
