@@ -664,6 +664,8 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
 struct DgradStackArgs {
     const bf16_t* da3; const bf16_t* a2; const bf16_t* a1; const bf16_t* w3; const bf16_t* w2;
     bf16_t* da2; bf16_t* da1; int batch;
+    // optional tail (W1): conv1's weight gradient of the same image, from da1 while it is still in LDS
+    const uint8_t* frames; const int* idx; float* gw1; float* gb1; long ws1, bs1; float scale1;
 };
 
 // LDS plan (bf16 elements).  da3 and a2 / da2 live in zero-bordered 11 x 11 grids, so every tap of the two
@@ -703,17 +705,38 @@ __device__ __forceinline__ void dgrad_issue(DgradRegs& r, const DgradStackArgs& 
     for (int i = 0; i < 2; ++i) { int t = tid + i * 256; r.d3[i] = s3[t < 392 ? t : 0]; }
 }
 
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* p0, const bf16_t* p1) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x4 lo = lds_tr4(p0), hi = lds_tr4(p1);
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 // MULTI: workgroups loop over images with the next image's inputs prefetched into registers.
-template <bool MULTI>
+// W1: the workgroup also accumulates conv1's weight gradient of its images (as conv1_wgrad_kernel does, wave w =
+// kernel channel w, im2col fragments gathered from the bf16 frame patch in place) with da1 read straight from
+// the LDS rows it was just written to: one launch, one round trip of da1 through memory and one dependent
+// index -> frame load chain less per step.
+template <bool MULTI, bool W1>
 __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     constexpr int P1 = 400, P2 = 81, P3 = 49, NRB3 = 6, NRB2 = 7;
+    constexpr int FH = 84, FW = 84;
+    constexpr long frame_bytes = 4L * FH * FW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, l15 = lane & 15;
     const int G = gridDim.x;
 
     DgradRegs in;
     int img = blockIdx.x;
+    PatchRegs pr;
+    long f_nxt = 0;
+    if constexpr (W1) {
+        const int i0 = img < a.batch ? img : 0;
+        const long f0 = a.idx ? (long)a.idx[i0] : (long)i0;
+        patch_issue_at<7>(pr, a.frames + f0 * frame_bytes, frame_bytes, tid);
+        if constexpr (MULTI) f_nxt = frame_index(a.idx, img + G, a.batch);
+    }
     dgrad_issue(in, a, img < a.batch ? img : 0, tid);       // flies under the weight staging
 
     // ---- weights: per-tap [o][c] tiles (T layout) -> fragments with rows = input channel, k = output channel
@@ -810,9 +833,28 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
         asm volatile("" : "+v"(ld2[rb]), "+v"(st2[rb]));
     }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // conv1 weight-gradient state (W1): transposing-read roles, accumulators
+    bf16_t* patch = lds + D_LDS_ELEMS;
+    const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    f32x4 acc1[2][4], accb1[2];
+    int boff[4];
+    bf16x8 ones;
+    if constexpr (W1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            accb1[i] = zero4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1[i][j] = zero4;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) boff[j] = wave * FH * FW + (2 * j + (tp >> 1)) * FW + 4 * (tp & 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+    }
 
     auto process = [&](int img) __attribute__((always_inline)) {
         __syncthreads();                    // previous image's gradients have left (and the grids are zeroed)
+        if constexpr (W1) patch_commit<7>(pr, frame_bytes, patch, tid);
 #pragma unroll
         for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(lds + in1[i]) = in.a1[i];
         if (tid < P1 * 4 - 1536) *reinterpret_cast<u32x4*>(lds + in1[6]) = in.a1[6];
@@ -823,6 +865,10 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
         if (tid < P3 * 8 - 256) *reinterpret_cast<u32x4*>(lds + in3[1]) = in.d3[1];
         __syncthreads();
         if constexpr (MULTI) dgrad_issue(in, a, img + G < a.batch ? img + G : 0, tid);   // unconditional: see cnn_fwd_stack_kernel
+        if constexpr (MULTI && W1) {
+            patch_issue_at<7>(pr, a.frames + f_nxt * frame_bytes, frame_bytes, tid);
+            f_nxt = frame_index(a.idx, img + 2 * G, a.batch);
+        }
 
         // ---- conv3^T: da2[(iy,ix)][c] = sum_{tap,o} w3[o][tap][c] da3[(iy-ky, ix-kx)][o], times relu'(a2).
         // Swapped product (weights as the A operand): a lane ends with 4 consecutive channels of one pixel.
@@ -925,11 +971,63 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
             for (int i = 0; i < 6; ++i) dst[tid + i * 256] = v[i];
             if (tid < P1 * 4 - 1536) dst[tid + 1536] = *reinterpret_cast<const uint4*>(lds + in1[6]);
         }
+        if constexpr (W1) {
+            // ---- conv1 weight gradient: dW1[o][(c, ky, kx)] += sum_px da1[px][o] patch[c][4 oy + ky][4 ox + kx];
+            // 13 chunks of 32 pixels; pixels >= 400 read the (always zero) first border row of the a2 grid
+            auto load = [&](bf16x8 (&fa)[2], bf16x8 (&fb)[4], int ch) {
+                int p0 = ch * 32 + 8 * tg + tq, p1 = p0 + 4;
+                int a0 = (p0 < P1 ? p0 * D1_CP : D_A2OFF) + 4 * tp, a1o = (p1 < P1 ? p1 * D1_CP : D_A2OFF) + 4 * tp;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = tr_frag(lds + a0 + i * 16, lds + a1o + i * 16);
+                int q0 = p0 < P1 ? p0 : 0, q1 = p1 < P1 ? p1 : 0;
+                const bf16_t* b0 = patch + (4 * (q0 / 20)) * FW + 4 * (q0 % 20);
+                const bf16_t* b1 = patch + (4 * (q1 / 20)) * FW + 4 * (q1 % 20);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = tr_frag(b0 + boff[j], b1 + boff[j]);
+            };
+            auto mma = [&](const bf16x8 (&fa)[2], const bf16x8 (&fb)[4]) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc1[i][j], 0, 0, 0);
+                    if (wave == 0) accb1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb1[i], 0, 0, 0);
+                }
+            };
+            bf16x8 fa0[2], fb0[4], fa1[2], fb1[4];
+            load(fa0, fb0, 0);
+#pragma unroll 1
+            for (int ch = 0; ch < 12; ch += 2) {        // chunks ch, ch + 1; fragments one chunk ahead
+                load(fa1, fb1, ch + 1);
+                mma(fa0, fb0);
+                load(fa0, fb0, ch + 2);
+                mma(fa1, fb1);
+            }
+            mma(fa0, fb0);                              // chunk 12
+        }
     };
     if (img < a.batch) {
         process(img);
         if constexpr (MULTI)
             for (img += G; img < a.batch; img += G) process(img);
+    }
+    if constexpr (W1) {
+        // partial [32][256] tile -> slab slice blockIdx.x (kernel layout == PyTorch's (c, ky, kx))
+        float* dw = a.gw1 + (long)blockIdx.x * a.ws1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int o = i * 16 + g4 * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int k = wave * 64 + j * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dw[(long)(o + r) * 256 + k] = acc1[i][j][r] * a.scale1;
+            }
+            if (wave == 0 && l15 == 0 && a.gb1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a.gb1[(long)blockIdx.x * a.bs1 + o + r] = accb1[i][r];
+            }
+        }
     }
 }
 
@@ -970,12 +1068,6 @@ __device__ __forceinline__ void wgrad_issue(WgradRegs& r, const WgradStackArgs& 
     for (int i = 0; i < 2; ++i) { int t = tid + i * 256; r.d3[i] = s4[t < 392 ? t : 0]; }
 }
 
-__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* p0, const bf16_t* p1) {
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    s16x4 lo = lds_tr4(p0), hi = lds_tr4(p1);
-    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
-}
 
 __global__ __launch_bounds__(256) void cnn_wgrad_stack_kernel(WgradStackArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
@@ -1224,25 +1316,43 @@ PDA_EXPORT void pda_cnn_fwd_stack(const void* const* frames, const void* const* 
 // of the Nature CNN from da3 [(b, 7x7)][64] in one launch (cnn_dgrad_stack_kernel).  84x84 inputs only.
 PDA_EXPORT int pda_cnn_dgrad_stack_supported(int H, int W, int C) { return (H == 84 && W == 84 && C == 4) ? 1 : 0; }
 
-PDA_EXPORT void pda_cnn_dgrad_stack(const void* da3, const void* a2, const void* a1, const void* w3, const void* w2,
-                                    void* da2, void* da1, int batch, hipStream_t stream) {
-    DgradStackArgs a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3,
-                        (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch};
-    size_t lds = (size_t)D_LDS_ELEMS * 2;   // >= the 9 x 4096-element weight staging tiles
+static void launch_dgrad_stack(DgradStackArgs& a, hipStream_t stream) {
+    const bool w1 = a.frames != nullptr;
+    size_t lds = ((size_t)D_LDS_ELEMS + (w1 ? 4 * 84 * 84 : 0)) * 2;   // >= the 9 x 4096-element weight staging tiles
     static_assert(D_LDS_ELEMS >= 9 * 4096, "weight staging must fit the working set's LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const void* fns[4] = {reinterpret_cast<const void*>(cnn_dgrad_stack_kernel<false, false>),
+                              reinterpret_cast<const void*>(cnn_dgrad_stack_kernel<true, false>),
+                              reinterpret_cast<const void*>(cnn_dgrad_stack_kernel<false, true>),
+                              reinterpret_cast<const void*>(cnn_dgrad_stack_kernel<true, true>)};
+        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    int blocks = batch < 256 ? batch : 256;         // one workgroup per CU (a wave owns its SIMD's register file)
-    if (blocks < batch)
-        hipLaunchKernelGGL(cnn_dgrad_stack_kernel<true>, dim3(blocks), dim3(256), lds, stream, a);
-    else
-        hipLaunchKernelGGL(cnn_dgrad_stack_kernel<false>, dim3(blocks), dim3(256), lds, stream, a);
+    int blocks = a.batch < 256 ? a.batch : 256;     // one workgroup per CU (a wave owns its SIMD's register file)
+    const bool multi = blocks < a.batch;
+    if (multi && w1) hipLaunchKernelGGL((cnn_dgrad_stack_kernel<true, true>), dim3(blocks), dim3(256), lds, stream, a);
+    else if (multi) hipLaunchKernelGGL((cnn_dgrad_stack_kernel<true, false>), dim3(blocks), dim3(256), lds, stream, a);
+    else if (w1) hipLaunchKernelGGL((cnn_dgrad_stack_kernel<false, true>), dim3(blocks), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((cnn_dgrad_stack_kernel<false, false>), dim3(blocks), dim3(256), lds, stream, a);
+}
+
+PDA_EXPORT void pda_cnn_dgrad_stack(const void* da3, const void* a2, const void* a1, const void* w3, const void* w2,
+                                    void* da2, void* da1, int batch, hipStream_t stream) {
+    DgradStackArgs a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3,
+                        (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch, nullptr, nullptr, nullptr, nullptr, 0, 0, 1.f};
+    launch_dgrad_stack(a, stream);
+}
+
+// same, plus conv1's weight gradient from uint8 frames (slab slice per workgroup: pda_cnn_dgrad_stack_slices(batch))
+PDA_EXPORT int pda_cnn_dgrad_stack_slices(int batch) { return batch < 256 ? batch : 256; }
+PDA_EXPORT void pda_cnn_dgrad_stack_w1(const void* da3, const void* a2, const void* a1, const void* w3, const void* w2,
+                                       void* da2, void* da1, int batch, const void* frames, const void* idx,
+                                       void* gw1, void* gb1, long ws1, long bs1, float scale1, hipStream_t stream) {
+    DgradStackArgs a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3,
+                        (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch, (const uint8_t*)frames, (const int*)idx,
+                        (float*)gw1, (float*)gb1, ws1, bs1, scale1};
+    launch_dgrad_stack(a, stream);
 }
 
 // conv2 + conv3 weight gradients of the Nature CNN, one slab slice per workgroup and layer (cnn_wgrad_stack_kernel).

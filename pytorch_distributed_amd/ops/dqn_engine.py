@@ -281,6 +281,9 @@ class DqnCnnEngine(object):
         self.pair_wgrad = bool(self.acts.stack_dgrad) and os.environ.get("PDA_PAIR_WGRAD", "1") != "0"
         # large batches: conv2 + conv3 weight gradients per image with register accumulation (csrc/conv1_kernels.hip)
         self.stack_wgrad = bool(self.acts.stack_dgrad) and self.B >= _WGRAD_STACK_MIN
+        # conv1's weight gradient as a tail of the dgrad stack launch (da1 still in LDS)
+        self.fuse_w1 = (bool(self.acts.stack_dgrad) and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32)
+                        and os.environ.get("PDA_FUSE_W1", "1") != "0")
         self._plan_wgrads()
         self._fc_pair = None
         self.idx = torch.zeros(self.B, dtype=torch.int32, device=dev)
@@ -325,6 +328,8 @@ class DqnCnnEngine(object):
             ns = nn.num_slices(red, ks) if ks > 0 else ns_override
             if li == 0 and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32):
                 ns = nn.conv1_wgrad_slices(B)       # whole-image kernel: one slice per workgroup
+                if self.fuse_w1:
+                    ns = nn.cnn_dgrad_stack_slices(B)   # computed by the dgrad stack launch itself
             plans.append((li, O, K, ks, ns))
         self.wg_plan = plans
         total = sum(ns * (O * K + O) for _, O, K, _, ns in plans)
@@ -447,7 +452,8 @@ class DqnCnnEngine(object):
         nn.linear_dgrad(a.dh1, on.w[3], a.a3[0], a.da3, B, g.HID, g.F, g.HID, g.F, g.F, g.F, act=nn.ACT_RELU)
         if a.stack_dgrad:
             # both conv data gradients in one launch (per-image, LDS-resident), then the two weight gradients
-            nn.cnn_dgrad_stack(a.da3, a.a2[0], a.a1[0], on.w[2], on.w[1], a.da2, a.da1, B)
+            nn.cnn_dgrad_stack(a.da3, a.a2[0], a.a1[0], on.w[2], on.w[1], a.da2, a.da1, B,
+                               w1=(s0, idx, w1s, b1s, 1.0 / self.norm_val) if self.fuse_w1 else None)
             if self.stack_wgrad:
                 nn.cnn_wgrad_stack(a.a1[0], a.a2[0], a.da2, a.da3, w2s, b2s, w3s, b3s, B)
             elif self.pair_wgrad:
@@ -463,8 +469,9 @@ class DqnCnnEngine(object):
         else:
             self._backward_conv_layerwise(a, on, B, M3, M2, on_side, (w3s, b3s, ks3, st3, bst3),
                                           (w2s, b2s, ks2, st2, bst2))
-        nn.conv_wgrad_u8(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / self.norm_val,
-                         ksplit=ks1, slice_stride=st1, bslice_stride=bst1)
+        if not (a.stack_dgrad and self.fuse_w1):
+            nn.conv_wgrad_u8(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / self.norm_val,
+                             ksplit=ks1, slice_stride=st1, bslice_stride=bst1)
         if fork:                # join: everything queued on the side stream (incl. fc wgrads put there by the caller)
             self.ev_side.record(side)
             cur.wait_event(self.ev_side)

@@ -111,11 +111,31 @@ def cnn_dgrad_stack_supported(H, W, C):
     return os.environ.get("PDA_FUSED_BWD", "1") != "0" and bool(_L().pda_cnn_dgrad_stack_supported(H, W, C))
 
 
-def cnn_dgrad_stack(da3, a2, a1, w3, w2, da2, da1, batch):
+def cnn_dgrad_stack_slices(batch):
+    L = _L()
+    L.pda_cnn_dgrad_stack_slices.argtypes = [ctypes.c_int]
+    L.pda_cnn_dgrad_stack_slices.restype = ctypes.c_int
+    return int(L.pda_cnn_dgrad_stack_slices(int(batch)))
+
+
+def cnn_dgrad_stack(da3, a2, a1, w3, w2, da2, da1, batch, w1=None):
     """da2 = conv3^T(da3) * relu'(a2), da1 = conv2^T(da2) * relu'(a1) for the Nature CNN on 84x84 inputs, one
-    workgroup per image with every intermediate in LDS (no dcol matrices, no col2im passes)."""
-    _L().pda_cnn_dgrad_stack(_ptr(da3), _ptr(a2), _ptr(a1), _ptr(w3), _ptr(w2), _ptr(da2), _ptr(da1), batch,
-                             _stream())
+    workgroup per image with every intermediate in LDS (no dcol matrices, no col2im passes).
+    w1 = (frames uint8, idx int32 or None, gw slab [slices][32*256], gb slab [slices][32], scale): the same launch
+    also leaves conv1's weight / bias gradient, one slab slice per workgroup (cnn_dgrad_stack_slices(batch))."""
+    L = _L()
+    if w1 is None:
+        L.pda_cnn_dgrad_stack(_ptr(da3), _ptr(a2), _ptr(a1), _ptr(w3), _ptr(w2), _ptr(da2), _ptr(da1), batch,
+                              _stream())
+        return
+    if not getattr(L, "_dgw1_ready", False):
+        L.pda_cnn_dgrad_stack_w1.argtypes = ([_vp] * 7 + [ctypes.c_int] + [_vp] * 4 + [ctypes.c_long, ctypes.c_long,
+                                             ctypes.c_float, _vp])
+        L.pda_cnn_dgrad_stack_w1.restype = None
+        L._dgw1_ready = True
+    frames, idx, gw, gb, scale = w1
+    L.pda_cnn_dgrad_stack_w1(_ptr(da3), _ptr(a2), _ptr(a1), _ptr(w3), _ptr(w2), _ptr(da2), _ptr(da1), int(batch),
+                             _ptr(frames), _ptr(idx), _ptr(gw), _ptr(gb), 32 * 256, 32, float(scale), _stream())
 
 
 def cnn_wgrad_stack_slices(batch):

@@ -226,6 +226,38 @@ def test_cnn_wgrad_stack_matches_torch(nn, batch):
     close(gb3, b3.grad, tol, 3e-3)
 
 
+@pytest.mark.parametrize("batch", [5, 300])
+def test_cnn_dgrad_stack_with_conv1_wgrad_tail(nn, batch):
+    """The dgrad stack launch with the conv1 weight-gradient tail: da2 / da1 identical to the plain launch, and
+    the conv1 gradient (from da1 still in LDS + the frame patch) == fp32 torch."""
+    torch.manual_seed(14)
+    mem = torch.randint(0, 256, (64, 4, 84, 84), dtype=torch.uint8, device="cuda")
+    idx = torch.randint(0, 64, (batch,), dtype=torch.int32, device="cuda")
+    a1 = bf(torch.relu(torch.randn(batch * 400, 32, device="cuda"))).bfloat16()
+    a2 = bf(torch.relu(torch.randn(batch * 81, 64, device="cuda"))).bfloat16()
+    da3 = bf(torch.randn(batch * 49, 64, device="cuda")).bfloat16()
+    w2 = bf(torch.randn(64, 512, device="cuda") / 22).bfloat16()
+    w3 = bf(torch.randn(64, 576, device="cuda") / 24).bfloat16()
+    ref2, ref1 = torch.zeros_like(a2), torch.zeros_like(a1)
+    nn.cnn_dgrad_stack(da3, a2, a1, w3, w2, ref2, ref1, batch)
+    ns = nn.cnn_dgrad_stack_slices(batch)
+    slab, bslab = torch.full((ns, 32 * 256), 7.0, device="cuda"), torch.full((ns, 32), 7.0, device="cuda")
+    da2, da1 = torch.zeros_like(a2), torch.zeros_like(a1)
+    nn.cnn_dgrad_stack(da3, a2, a1, w3, w2, da2, da1, batch, w1=(mem, idx, slab, bslab, 1.0 / 255.0))
+    torch.cuda.synchronize()
+    assert torch.equal(da2, ref2) and torch.equal(da1, ref1)
+    gw, gb = torch.zeros(32, 256, device="cuda"), torch.zeros(32, device="cuda")
+    nn.ReducePlan([(slab, gw, 32 * 256, ns, 32 * 256), (bslab, gb, 32, ns, 32)]).run()
+    x = mem[idx.long()].float() / 255.0
+    w = torch.zeros(32, 4, 8, 8, device="cuda", requires_grad=True)
+    b = torch.zeros(32, device="cuda", requires_grad=True)
+    dy = da1.float().view(batch, 20, 20, 32).permute(0, 3, 1, 2).contiguous()
+    F.conv2d(x, w, b, stride=4).backward(dy)
+    tol = 2e-3 * max(1.0, batch / 8) ** 0.5 * float(dy.abs().max())
+    close(gw.reshape(32, 4, 8, 8), w.grad, tol, 3e-3)
+    close(gb, b.grad, tol, 3e-3)
+
+
 @pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("batch", [8, 300])
 def test_conv1_wgrad_u8(nn, batch, generic, monkeypatch):
