@@ -425,24 +425,30 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16_t* lds, int r0, int ks, i
     }
 }
 
+template <int BM, int BN, int BK, class SA, class SB>
+constexpr int gemm_lds_elems() {
+    return 2 * (LdsShape<SA::kT, BM, BK>::kElems + LdsShape<SB::kT, BN, BK>::kElems);
+}
+
+// The work of one workgroup.  (bx, by, bz) = (tile, k-slice, problem group): blockIdx for a plain launch, a
+// decoded linear index when two GEMMs share one launch (gemm_duo_kernel).
 template <int BM, int BN, int WM, int WN, int BK, class SA, class SB, class EP>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs<SA, SB, EP> args) {
+__device__ __forceinline__ void gemm_body(const GemmArgs<SA, SB, EP>& args, int bx, int by, int bz, bf16_t* lds) {
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
     static_assert(FM >= 1 && FN >= 1, "tile too small for the wave grid");
     constexpr bool TA = SA::kT, TB = SB::kT;
     constexpr int A_ELEMS = LdsShape<TA, BM, BK>::kElems, B_ELEMS = LdsShape<TB, BN, BK>::kElems;
-    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (A_ELEMS + B_ELEMS)];
 
-    const GemmGroup<SA, SB, EP>& G = args.g[blockIdx.z];
+    const GemmGroup<SA, SB, EP>& G = args.g[bz];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile_m = blockIdx.x / args.tiles_n, tile_n = blockIdx.x % args.tiles_n;
+    const int tile_m = bx / args.tiles_n, tile_n = bx % args.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (m0 >= G.M || n0 >= G.N) return;     // groups may differ in size
     int kbeg = 0, kend = G.K;
     if (args.ksplit > 0) {
-        kbeg = blockIdx.y * args.ksplit;
+        kbeg = by * args.ksplit;
         kend = min(G.K, kbeg + args.ksplit);
         if (kbeg >= kend) return;
     }
@@ -526,6 +532,46 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs<SA, SB, EP>
             for (int r = 0; r < 4; ++r) G.e.bias_grad(m + r, accb[i][r], G.M);
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int BK, class SA, class SB, class EP>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs<SA, SB, EP> args) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[gemm_lds_elems<BM, BN, BK, SA, SB>()];
+    gemm_body<BM, BN, WM, WN, BK, SA, SB, EP>(args, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+}
+
+// Two independent GEMMs in ONE launch (horizontal fusion): workgroups [0, n1) run the first, the rest the second.
+// For pairs of under-filled launches with no dependence on each other (fc1's data gradient: 196 workgroups, and
+// the two fc weight gradients) that would otherwise run back to back.  grid1 = (tiles, k-slices, groups) of the
+// first problem; the second is decoded the same way from the remaining indices.
+template <int BM1, int BN1, int WM1, int WN1, class SA1, class SB1, class EP1,
+          int BM2, int BN2, int WM2, int WN2, class SA2, class SB2, class EP2, int BK = GEMM_BK>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_duo_kernel(GemmArgs<SA1, SB1, EP1> a1, int3 grid1,
+                                                                GemmArgs<SA2, SB2, EP2> a2, int3 grid2) {
+    constexpr int L1 = gemm_lds_elems<BM1, BN1, BK, SA1, SB1>(), L2 = gemm_lds_elems<BM2, BN2, BK, SA2, SB2>();
+    __shared__ __attribute__((aligned(16))) bf16_t lds[L1 > L2 ? L1 : L2];
+    int b = blockIdx.x;
+    const int n1 = grid1.x * grid1.y * grid1.z;
+    if (b < n1) {
+        gemm_body<BM1, BN1, WM1, WN1, BK, SA1, SB1, EP1>(a1, b % grid1.x, (b / grid1.x) % grid1.y, b / (grid1.x * grid1.y), lds);
+    } else {
+        b -= n1;
+        gemm_body<BM2, BN2, WM2, WN2, BK, SA2, SB2, EP2>(a2, b % grid2.x, (b / grid2.x) % grid2.y, b / (grid2.x * grid2.y), lds);
+    }
+}
+
+// grid of launch_gemm for these sizes (also fills tiles_n / ksplit): for launches that share a kernel
+template <int BM, int BN, class SA, class SB, class EP, int BK = GEMM_BK>
+static int3 plan_gemm(GemmArgs<SA, SB, EP>& args, int ngroups, int maxM, int maxN, int maxK, int ksplit) {
+    int tiles_m = (maxM + BM - 1) / BM, tiles_n = (maxN + BN - 1) / BN;
+    args.tiles_n = tiles_n;
+    int nsplit = 1;
+    if (ksplit > 0) {
+        ksplit = (ksplit + BK - 1) / BK * BK;
+        nsplit = (maxK + ksplit - 1) / ksplit;
+    }
+    args.ksplit = ksplit > 0 ? ksplit : 0;
+    return make_int3(tiles_m * tiles_n, nsplit, ngroups);
 }
 
 template <int BM, int BN, int WM, int WN, class SA, class SB, class EP, int BK = GEMM_BK>

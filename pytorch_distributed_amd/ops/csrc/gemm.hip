@@ -174,6 +174,36 @@ PDA_EXPORT void pda_linear_wgrad2(const void* const* dy, const void* const* x, v
     launch_gemm<64, 64, 2, 2>(a, 2, maxM, maxN, B, 0, stream);
 }
 
+// fc backward in one launch: the data gradient of one linear layer (pda_linear_dgrad's problem, 32-row tiles) and the
+// two single-slice weight gradients of pda_linear_wgrad2 -- independent of each other, all ready after the head.
+PDA_EXPORT void pda_fc_backward_duo(const void* d_dy, const void* d_w, const void* d_y, void* d_dx, int M, int Nout,
+                                    int Kin, long lddy, long ldw, long ldy, long lddx, int act,
+                                    const void* const* dy, const void* const* x, void* const* gw, void* const* gb,
+                                    int B, const int* wNout, const int* wKin, const long* wlddy, const long* wldx,
+                                    const long* wldg, hipStream_t stream) {
+    GemmArgs<SrcDenseK, SrcDenseT, EpiMaskBf16> a1;
+    a1.g[0].a = {(const bf16_t*)d_dy, lddy, M, Nout};
+    a1.g[0].b = {(const bf16_t*)d_w, ldw, Kin, Nout};
+    a1.g[0].e = {(bf16_t*)d_dx, (const bf16_t*)d_y, d_y ? act : ACT_NONE, lddx, ldy};
+    a1.g[0].M = M; a1.g[0].N = Kin; a1.g[0].K = Nout;
+    int3 g1 = plan_gemm<32, 64>(a1, 1, M, Kin, Nout, 0);
+    GemmArgs<SrcDenseT, SrcDenseT, EpiWgrad> a2;
+    int maxM = 0, maxN = 0;
+    for (int i = 0; i < 2; ++i) {
+        a2.g[i].a = {(const bf16_t*)dy[i], wlddy[i], wNout[i], B};
+        a2.g[i].b = {(const bf16_t*)x[i], wldx[i], wKin[i], B};
+        a2.g[i].e = {(float*)gw[i], (float*)gb[i], wldg[i], 0, 0, 1.f};
+        a2.g[i].M = wNout[i]; a2.g[i].N = wKin[i]; a2.g[i].K = B;
+        maxM = wNout[i] > maxM ? wNout[i] : maxM;
+        maxN = wKin[i] > maxN ? wKin[i] : maxN;
+    }
+    int3 g2 = plan_gemm<64, 64>(a2, 2, maxM, maxN, B, 0);
+    int blocks = g1.x * g1.y * g1.z + g2.x * g2.y * g2.z;
+    hipLaunchKernelGGL((gemm_duo_kernel<32, 64, 1, 4, SrcDenseK, SrcDenseT, EpiMaskBf16,
+                                        64, 64, 2, 2, SrcDenseT, SrcDenseT, EpiWgrad>),
+                       dim3(blocks), dim3(GEMM_THREADS), 0, stream, a1, g1, a2, g2);
+}
+
 // conv, NHWC bf16 input: gw[O][(ky,kx,c)] = sum_m dy[m][o] * im2col(x)[m][k]
 PDA_EXPORT void pda_conv_wgrad(const void* dy, const void* x, void* gw, void* gb, int batch, int H, int W, int C,
                                int KH, int KW, int S, int O, long slice_stride, long bslice_stride, int ksplit,

@@ -281,6 +281,8 @@ class DqnCnnEngine(object):
         self.pair_wgrad = bool(self.acts.stack_dgrad) and os.environ.get("PDA_PAIR_WGRAD", "1") != "0"
         # large batches: conv2 + conv3 weight gradients per image with register accumulation (csrc/conv1_kernels.hip)
         self.stack_wgrad = bool(self.acts.stack_dgrad) and self.B >= _WGRAD_STACK_MIN
+        # fc1's data gradient in the launch of the two fc weight gradients (small batches: all three under-fill the GPU)
+        self.fc_duo = self.B <= 512 and not self.overlap_wgrad_env() and os.environ.get("PDA_FC_DUO", "1") != "0"
         # conv1's weight gradient as a tail of the dgrad stack launch (da1 still in LDS)
         self.fuse_w1 = (bool(self.acts.stack_dgrad) and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32)
                         and os.environ.get("PDA_FUSE_W1", "1") != "0")
@@ -409,6 +411,10 @@ class DqnCnnEngine(object):
             B=B, HID=g.HID, A=g.A, rng_counter=_p(self.counter), opt_step=_p(self.adam.step_dev))
         _L().pda_dqn_head(ctypes.byref(args), _stream())
 
+    @staticmethod
+    def overlap_wgrad_env():
+        return os.environ.get("PDA_OVERLAP_WGRAD", "0") == "1"
+
     def backward_fc(self):
         g, B, a = self.geom, self.B, self.acts
         # one slice each, written straight into the gradient buffer (kernel layout); both in one launch
@@ -416,7 +422,13 @@ class DqnCnnEngine(object):
             self._fc_pair = nn.LinearWgradPair(
                 [(a.dh1, a.a3[0], self.gw[3], self.gb[3], g.HID, g.F, g.HID, g.F, g.F),
                  (a.dq, a.h1, self.gw[4], self.gb[4], g.A, g.HID, a.dq_ld, g.HID, g.HID)], B)
-        self._fc_pair.run()
+        if self.fc_duo:
+            # ... and fc1's data gradient rides in the same launch (backward_conv then starts at the conv stack)
+            on = self.online
+            self._fc_pair.run_with_dgrad(a.dh1, on.w[3], a.a3[0], a.da3, B, g.HID, g.F, g.HID, g.F, g.F, g.F,
+                                         act=nn.ACT_RELU)
+        else:
+            self._fc_pair.run()
 
     def fused_extras(self, staged, slabs=True):
         """AdamExtras: (single-rank steps) slab sums in the optimizer launch, plus (device replay,
@@ -449,7 +461,8 @@ class DqnCnnEngine(object):
                 side.wait_event(ready)
                 fn()
 
-        nn.linear_dgrad(a.dh1, on.w[3], a.a3[0], a.da3, B, g.HID, g.F, g.HID, g.F, g.F, g.F, act=nn.ACT_RELU)
+        if not self.fc_duo:
+            nn.linear_dgrad(a.dh1, on.w[3], a.a3[0], a.da3, B, g.HID, g.F, g.HID, g.F, g.F, g.F, act=nn.ACT_RELU)
         if a.stack_dgrad:
             # both conv data gradients in one launch (per-image, LDS-resident), then the two weight gradients
             nn.cnn_dgrad_stack(a.da3, a.a2[0], a.a1[0], on.w[2], on.w[1], a.da2, a.da1, B,

@@ -253,6 +253,21 @@ class LinearWgradPair(object):
         _L().pda_linear_wgrad2(self.dy, self.x, self.gw, self.gb, self.B, self.nout, self.kin, self.lddy,
                                self.ldx, self.ldg, _stream())
 
+    def run_with_dgrad(self, dy, w, y, dx, M, Nout, Kin, lddy, ldw, ldy, lddx, act=ACT_NONE):
+        """The same two weight gradients plus linear_dgrad(dy, w, y, dx, ...) in ONE launch
+        (csrc/gemm.h:gemm_duo_kernel): the three are independent and each under-fills the GPU."""
+        L = _L()
+        if not getattr(L, "_duo_ready", False):
+            c_int, c_long = ctypes.c_int, ctypes.c_long
+            L.pda_fc_backward_duo.argtypes = ([_vp] * 4 + [c_int] * 3 + [c_long] * 4 + [c_int] + [_vp] * 4 + [c_int] +
+                                              [_vp] * 5 + [_vp])
+            L.pda_fc_backward_duo.restype = None
+            L._duo_ready = True
+        assert lddy % 8 == 0 and ldw % 8 == 0
+        L.pda_fc_backward_duo(_ptr(dy), _ptr(w), _ptr(y), _ptr(dx), M, Nout, Kin, lddy, ldw, ldy, lddx, act,
+                              self.dy, self.x, self.gw, self.gb, self.B, self.nout, self.kin, self.lddy,
+                              self.ldx, self.ldg, _stream())
+
 
 def conv_wgrad(dy, x, gw, gb, batch, H, W, C, KH, KW, S, O, ksplit=0, slice_stride=0, bslice_stride=0):
     """gw[O][(ky,kx,c)] slices (see linear_wgrad); x is NHWC bf16."""
