@@ -31,6 +31,7 @@ Here a step is ~20 launches captured in one hipGraph, all on data resident in HB
 MLP-DQN (dqn-mlp, D->256->256->256->A) reuses the DQN head kernel with HID=256.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -451,13 +452,22 @@ class MlpStepProgram(object):
     """[sample, stage, forward, head, backward] | all-reduce(flat grads) | [adam, target, tree repair];
     one hipGraph per bracket (a single graph when there is one rank)."""
 
-    def __init__(self, engine, comm=None, use_graph=True, staged=False, force_dp=False):
+    def __init__(self, engine, comm=None, use_graph=True, staged=False, force_dp=False, graph_steps=1):
         self.e, self.comm, self.staged = engine, comm, staged
         self.world = comm.world_size if comm is not None else 1
         self.dp = comm is not None and (self.world > 1 or force_dp)
         self.use_graph = use_graph
         self.graphs = None
         self.calls = 0
+        # updates per graph replay (single rank, device replay): see ops/dqn_engine.py:DqnStepProgram
+        k = int(os.environ.get("PDA_GRAPH_STEPS", graph_steps) or 1)
+        if self.dp or staged or not use_graph:
+            k = 1
+        tu = engine.target_update
+        if k > 1 and tu >= 1.0:
+            while k > 1 and int(tu) % k != 0:
+                k -= 1
+        self.graph_steps, self.ahead = max(1, k), 0
         if self.dp:     # the all-reduce is a SUM; Adam applies the 1/world_size
             engine.adam.set_grad_scale(1.0 / self.world)
 
@@ -485,6 +495,11 @@ class MlpStepProgram(object):
 
     def step(self):
         e = self.e
+        if self.ahead > 0:              # already performed by the last multi-step replay
+            self.ahead -= 1
+            self.calls += 1
+            return
+        done = 1
         if not self.use_graph or self.calls == 0:
             if not self.dp:
                 self._all()
@@ -494,15 +509,21 @@ class MlpStepProgram(object):
                 self._part_c()
         else:
             if self.graphs is None:
-                self.graphs = self._capture([self._part_a, self._part_c] if self.dp else [self._all])
+                def k_steps():
+                    for _ in range(self.graph_steps):
+                        self._all()
+                self.graphs = self._capture([self._part_a, self._part_c] if self.dp else [k_steps])
             if not self.dp:
                 self.graphs[0].replay()
+                done = self.graph_steps
+                self.ahead = done - 1
             else:
                 self.graphs[0].replay()
                 self.comm.all_reduce_sum_(e.grads)
                 self.graphs[1].replay()
         self.calls += 1
-        e.loss_steps += 1
+        e.loss_steps += done
+        e.step_count += done - 1
         if e.target_update >= 1.0 and e.step_count % int(e.target_update) == 0:
             e.hard_target_update()
         e.step_count += 1
@@ -538,7 +559,8 @@ class MlpNativeCore(object):
         else:
             self.engine.make_staging(a + 3 * k + 1)
         self.program = MlpStepProgram(self.engine, comm, use_graph=use_graph, staged=not self.on_device,
-                                      force_dp=bool(getattr(args, "force_dp", False)))
+                                      force_dp=bool(getattr(args, "force_dp", False)),
+                                      graph_steps=int(getattr(args, "graph_steps", 1)))
         self._last_size = -1
         self.step_count = 0
 
