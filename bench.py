@@ -82,6 +82,10 @@ def main():
         "agent_params.batch_size": a.batch}))
     if a.graph_steps is not None:
         opt.graph_steps = int(a.graph_steps)
+    else:
+        # the learner replays several updates per hipGraph and runs ahead of its caller (options.graph_steps): pick a
+        # count that divides --steps, so that EXACTLY that many updates execute inside the timed window
+        opt.graph_steps = max(d for d in range(1, int(opt.graph_steps) + 1) if a.steps % d == 0)
     ap_ = opt.agent_params
     torch.manual_seed(opt.seed)
 
@@ -116,6 +120,9 @@ def main():
         raise RuntimeError("native compute requested but the HIP engine is not in use")
 
     for _ in range(a.warmup):
+        core.step()
+    prog = getattr(core, "program", None)
+    while prog is not None and getattr(prog, "ahead", 0) > 0:   # end the warm-up on a replay boundary (untimed extras)
         core.step()
     torch.cuda.synchronize()
     comm.barrier()
