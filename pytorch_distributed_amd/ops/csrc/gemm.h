@@ -300,8 +300,8 @@ struct EpiDgradScatter {
     __device__ __forceinline__ void bias_grad(int, float, int) const {}
 };
 
-// weight gradient: plain stores of this block's split-K partial tile into slab slice
-// blockIdx.y, in GEMM (kernel) layout [m][n].  A single-slice launch writes the gradient
+// weight gradient: plain stores of this block's split-K partial tile into its slab slice
+// (epi_for_slice below points gw / gb at it), in GEMM (kernel) layout [m][n].  A single-slice launch writes the gradient
 // buffer itself; multi-slice launches write a scratch slab that wgrad_reduce_kernel sums.
 // (fp32 atomics execute memory-side on MI355X and the PyTorch-layout scatter made every
 // lane its own 64-B request: 134 us per conv wgrad in the first profile.)
@@ -310,15 +310,24 @@ struct EpiWgrad {
     static constexpr bool kBiasGrad = true;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N) const {
         if (n >= N) return;
-        float* dst = gw + (long)blockIdx.y * slice_stride;
+        float* dst = gw;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (m + r < M) dst[(long)(m + r) * ld + n] = v[r] * scale;
     }
     __device__ __forceinline__ void bias_grad(int m, float v, int M) const {
-        if (gb && m < M) gb[(long)blockIdx.y * bslice_stride + m] = v;
+        if (gb && m < M) gb[m] = v;
     }
 };
+// the epilogue of split-K slice `by` (the slice index is an argument, not blockIdx.y: launches that carry
+// several kernels' workgroups decode their own linear block index)
+template <class EP> __device__ __forceinline__ EP epi_for_slice(const EP& e, int) { return e; }
+__device__ __forceinline__ EpiWgrad epi_for_slice(const EpiWgrad& e, int by) {
+    EpiWgrad r = e;
+    r.gw += (long)by * e.slice_stride;
+    if (r.gb) r.gb += (long)by * e.bslice_stride;
+    return r;
+}
 
 // ----------------------------------------------------------------------------
 // kernel
@@ -519,17 +528,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<SA, SB, EP>& args, int 
     }
 
     // C/D layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
+    const EP ep = epi_for_slice(G.e, args.ksplit > 0 ? by : 0);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         int m = m0 + wm * (BM / WM) + i * 16 + (lane >> 4) * 4;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             int n = n0 + wn * (BN / WN) + j * 16 + (lane & 15);
-            G.e(m, n, acc[i][j], G.M, G.N);
+            ep(m, n, acc[i][j], G.M, G.N);
         }
         if (do_bias && (lane & 15) == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) G.e.bias_grad(m + r, accb[i][r], G.M);
+            for (int r = 0; r < 4; ++r) ep.bias_grad(m + r, accb[i][r], G.M);
         }
     }
 }

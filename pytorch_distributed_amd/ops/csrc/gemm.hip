@@ -4,6 +4,7 @@
 // learner steps into a hipGraph.
 #include "gemm.h"
 #include "api.h"
+#include "optim.h"
 #include <cstdlib>
 
 namespace {
@@ -239,6 +240,60 @@ PDA_EXPORT void pda_conv_wgrad_pair(const void* const* dy, const void* const* x,
         if (M > maxK) maxK = M;
     }
     launch_gemm<64, 64, 2, 2>(a, 2, O, maxN, maxK, ksplit, stream);
+}
+
+// The conv2 / conv3 weight-gradient pair and the optimizer update of the fc tail in ONE launch.  At batch 128 the
+// fc gradients are final before the conv ones are (the fc backward runs first), and 95 % of the parameters are
+// fc1's: their Adam workgroups stream HBM while the GEMM workgroups of the pair sit in MFMA / LDS latency, instead
+// of the two launches running back to back (10.8 + 13.9 us).  The conv head of the optimizer follows as a short
+// launch of its own (rl_kernels.hip: pda_adam_x with the head table).
+// Measured: the step gets SLOWER (85.0 vs 79.9 us) -- the co-resident Adam streams delay the GEMM workgroups' operand
+// loads -- so the engine only takes this path on request (PDA_PAIR_ADAM=1, ops/dqn_engine.py).
+struct AdamLaunch {
+    float *p, *g, *m, *v; bf16_t* shadow; const SegEntry* segs; const int2* chunks; int nchunks;
+    const float* hyper; const int* step;
+};
+__global__ __launch_bounds__(GEMM_THREADS) void adam_wgrad_pair_kernel(GemmArgs<SrcDenseT, SrcIm2colT, EpiWgrad> wg,
+                                                                       int3 grid, AdamLaunch A) {
+    constexpr int LG = gemm_lds_elems<64, 64, GEMM_BK, SrcDenseT, SrcIm2colT>() * (int)sizeof(bf16_t);
+    constexpr int LA = OPT_ROW_LDS * (int)sizeof(float);
+    __shared__ __attribute__((aligned(16))) char lds[LG > LA ? LG : LA];
+    int b = blockIdx.x;
+    const int ng = grid.x * grid.y * grid.z;
+    if (b < ng) {       // the GEMM workgroups first: they are the longer ones
+        gemm_body<64, 64, 2, 2, GEMM_BK, SrcDenseT, SrcIm2colT, EpiWgrad>(wg, b % grid.x, (b / grid.x) % grid.y,
+                                                                           b / (grid.x * grid.y),
+                                                                           reinterpret_cast<bf16_t*>(lds));
+    } else {
+        AdamExtras x = {};
+        adam_block(A.p, A.g, A.m, A.v, A.shadow, A.segs, A.chunks, A.nchunks, A.hyper, A.step, x, b - ng,
+                   reinterpret_cast<float*>(lds));
+    }
+}
+PDA_EXPORT void pda_adam_with_wgrad_pair(const void* const* dy, const void* const* x, void* const* gw, void* const* gb,
+                                         int batch, const int* H, const int* W, const int* C, const int* KH,
+                                         const int* KW, const int* S, int O, const long* slice_stride,
+                                         const long* bslice_stride, int ksplit,
+                                         void* p, void* g, void* m, void* v, void* shadow, const void* segs,
+                                         const void* chunks, int nchunks, const void* hyper, void* step,
+                                         hipStream_t stream) {
+    GemmArgs<SrcDenseT, SrcIm2colT, EpiWgrad> a;
+    int maxN = 0, maxK = 0;
+    for (int i = 0; i < 2; ++i) {
+        ConvGeom geo = make_geom(H[i], W[i], C[i], KH[i], KW[i], S[i]);
+        int M = batch * geo.OH * geo.OW, K = C[i] * KH[i] * KW[i];
+        a.g[i].a = {(const bf16_t*)dy[i], (long)O, O, M};
+        a.g[i].b = {(const bf16_t*)x[i], geo, K, M};
+        a.g[i].e = {(float*)gw[i], (float*)gb[i], (long)K, slice_stride[i], bslice_stride[i], 1.f};
+        a.g[i].M = O; a.g[i].N = K; a.g[i].K = M;
+        if (K > maxN) maxN = K;
+        if (M > maxK) maxK = M;
+    }
+    int3 grid = plan_gemm<64, 64>(a, 2, O, maxN, maxK, ksplit);
+    AdamLaunch A = {(float*)p, (float*)g, (float*)m, (float*)v, (bf16_t*)shadow, (const SegEntry*)segs,
+                    (const int2*)chunks, nchunks, (const float*)hyper, (const int*)step};
+    hipLaunchKernelGGL(adam_wgrad_pair_kernel, dim3(grid.x * grid.y * grid.z + nchunks), dim3(GEMM_THREADS), 0,
+                       stream, a, grid, A);
 }
 
 // conv1 from uint8 frames: gw[O][(c,ky,kx)] (== PyTorch's own order)

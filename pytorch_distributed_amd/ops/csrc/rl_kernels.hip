@@ -2,6 +2,7 @@
 // priorities), critic TD for DDPG, fused Adam / Polyak over flat buffers with
 // bf16 shadow-weight emission, epsilon-greedy actor epilogue.
 #include "api.h"
+#include "optim.h"
 
 // ----------------------------------------------------------------------------
 // DQN head.  One wave64 per sample; the 512-wide hidden row is 8 values per lane.
@@ -244,75 +245,7 @@ PDA_EXPORT void pda_td_vector(const void* q, const void* next_q, const void* tai
                        (unsigned long long*)rng_counter, (int*)opt_step);
 }
 
-// ----------------------------------------------------------------------------
-// flat-buffer optimizer.  One launch updates every parameter, clips the gradient
-// by value and emits the bf16 "shadow" weights in the layout the MFMA kernels
-// read.  Weights that have a shadow keep their gradient and Adam moments in that
-// same kernel layout ([row][p*C + c]: what the wgrad GEMMs produce with coalesced
-// stores); only the fp32 master stays in PyTorch's layout ([row][c*P + p]).  Threads
-// walk kernel order, so g/m/v/shadow accesses are coalesced and the strided master
-// accesses stay inside one row (<= 12.5 KB), which the vector L1 absorbs.
-// Segment table entry (8 ints): start, count, cols, C, P, shadow_off, shadow_ld, flags(1 = has shadow)
-// hyper (device floats): lr, beta1, beta2, eps, weight_decay, clip, grad_scale
-// step: number of updates including this one (bumped earlier in the step, see dqn_head_kernel / pda_tick)
-// ----------------------------------------------------------------------------
-struct SegEntry { int start, count, cols, C, P, shadow_off, shadow_ld, flags; };
-
-// kernel-order element j of segment s -> index of its fp32 master
-__device__ __forceinline__ long master_index(const SegEntry& s, int j, long* shadow_idx) {
-    if (!(s.flags & 1)) { *shadow_idx = -1; return (long)s.start + j; }
-    int row = j / s.cols, q = j - row * s.cols;
-    int pp = q / s.C, c = q - pp * s.C;
-    *shadow_idx = (long)s.shadow_off + (long)row * s.shadow_ld + q;
-    return (long)s.start + (long)row * s.cols + c * s.P + pp;
-}
-
-// Optional work folded into the optimizer launch (each saves a ~4-8 us kernel of the 20-kernel step):
-//   * split-K gradient slabs are summed here instead of by wgrad_reduce_kernel (single-rank steps;
-//     a data-parallel step needs the reduced gradient before the all-reduce and keeps the reduce launch)
-//   * the uniform replay indices of the NEXT step are drawn by extra blocks of this launch: every
-//     consumer of the current indices has finished by now, and the rng counter was bumped by the head
-struct AdamExtras {
-    const float* slab; const int4* slabinfo;        // per segment (slab_off, nslices, slice_stride, -)
-    int* next_idx; float* next_w; int next_B; const int* size; unsigned long long seed;
-    const unsigned long long* counter;
-};
-
-#define OPT_CHUNK 2048      // elements per block (flat chunks)
-#define OPT_ROW_LDS 4352    // floats of LDS for one weight row in the transposition path (row pitch padded to odd)
-
-// A chunk is (segment, first element).  Segments whose master layout is a per-row transpose of the
-// kernel layout (C > 1: conv2/conv3/fc1 weights) are chunked one ROW per block when the row fits in
-// LDS; everything else in flat OPT_CHUNK pieces.  (ops/optim.py:SegmentTable builds the list.)
-__device__ __forceinline__ bool row_mode(const SegEntry& s) {
-    return (s.flags & 1) && s.C > 1 && (s.P | 1) * s.C <= OPT_ROW_LDS;
-}
-// flags bit 1: "fine" flat chunks of 64 elements (segments whose gradient is summed from many split-K slabs
-// inside the optimizer): a lane per element, the slices dealt over the 4 waves of the workgroup
-__device__ __forceinline__ int chunk_len(const SegEntry& s) {
-    return row_mode(s) ? s.cols : ((s.flags & 2) ? 64 : OPT_CHUNK);
-}
-
-// gradient element e (kernel order within segment seg): the flat buffer, or the sum of the split-K slabs
-__device__ __forceinline__ float grad_at(const AdamExtras& x, int seg, int e, float* g, long i) {
-    if (x.slab == nullptr) return g[i];
-    int4 si = x.slabinfo[seg];
-    if (si.y <= 0) return g[i];
-    const float* q = x.slab + si.x + e;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int sl = 0;
-    for (; sl + 4 <= si.y; sl += 4) {
-        a0 += q[(long)sl * si.z];
-        a1 += q[(long)(sl + 1) * si.z];
-        a2 += q[(long)(sl + 2) * si.z];
-        a3 += q[(long)(sl + 3) * si.z];
-    }
-    for (; sl < si.y; ++sl) a0 += q[(long)sl * si.z];
-    float gi = (a0 + a1) + (a2 + a3);
-    g[i] = gi;          // keep the flat gradient readable (tests, debugging)
-    return gi;
-}
-
+// flat-buffer optimizer (optim.h): segment table, chunk rules, adam_block
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16_t* __restrict__ shadow, const SegEntry* __restrict__ segs,
@@ -320,190 +253,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    const float* __restrict__ hyper,
                                                    const int* __restrict__ step, AdamExtras x) {
     __shared__ float row[OPT_ROW_LDS];
-    if ((int)blockIdx.x >= nchunks) {       // sampler blocks (only launched when x.next_idx is set)
-        int i = ((int)blockIdx.x - nchunks) * 256 + threadIdx.x;
-        if (i < x.next_B) {
-            unsigned long long ctr = *x.counter;
-            int n = max(*x.size, 1);
-            uint32_t r = hash_u32(x.seed ^ (ctr * 0x9e3779b97f4a7c15ULL + (unsigned long long)i + 1));
-            x.next_idx[i] = (int)(((unsigned long long)r * (unsigned long long)n) >> 32);
-            if (x.next_w) x.next_w[i] = 1.f;
-        }
-        return;
-    }
-    int2 ch = chunks[blockIdx.x];           // (segment, first element within the segment)
-    SegEntry s = segs[ch.x];
-    float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], clip = hyper[5],
-          gscale = hyper[6];
-    float t = (float)max(*step, 1);
-    float bc1 = 1.f - __powf(b1, t), bc2 = 1.f - __powf(b2, t);
-    float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
-    if (row_mode(s)) {
-        // One weight row.  The fp32 master keeps PyTorch's [c][p] order, gradients / moments / bf16 shadow
-        // the kernels' [p][c] order.  Walking kernel order against the master directly costs one 64-byte
-        // sector per 4-byte access (24 us for the 1.6 M fc1 weights); here the master row crosses LDS:
-        // coalesced in, transposed access in LDS (the pitch P, padded to odd, spreads the banks),
-        // coalesced out.
-        int r = ch.y / s.cols;
-        float* prow = p + (long)s.start + (long)r * s.cols;
-        int P = s.P, C = s.C, pitch = P | 1;
-        const long gbase0 = (long)s.start + (long)r * s.cols;
-        const long sbase0 = (long)s.shadow_off + (long)r * s.shadow_ld;
-        const bool summed = x.slab != nullptr && x.slabinfo[ch.x].y > 0;
-        if (!summed && ((C | s.cols | (int)gbase0 | (int)sbase0) & 3) == 0) {
-            // 16-byte path (fc1: 512 rows of 3136 = 95 % of the parameters).  Every load of a phase is issued
-            // before the first use: the scalar loops below make ~13 dependent round trips per row, which kept
-            // this launch at 3.4 TB/s.
-            constexpr int IT = (OPT_ROW_LDS + 1023) / 1024;
-            float4 a4[IT], m4[IT], v4[IT];
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                int i = (threadIdx.x + it * 256) * 4;
-                if (i < s.cols) a4[it] = *reinterpret_cast<const float4*>(prow + i);
-            }
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                int i = (threadIdx.x + it * 256) * 4;
-                if (i < s.cols) {
-                    const float e4[4] = {a4[it].x, a4[it].y, a4[it].z, a4[it].w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        int c = (i + k) / P, pp = (i + k) - c * P;
-                        row[c * pitch + pp] = e4[k];
-                    }
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {       // gradient / moments: kernel order, coalesced
-                int q = (threadIdx.x + it * 256) * 4;
-                if (q < s.cols) {
-                    a4[it] = *reinterpret_cast<const float4*>(g + gbase0 + q);
-                    m4[it] = *reinterpret_cast<const float4*>(m + gbase0 + q);
-                    v4[it] = *reinterpret_cast<const float4*>(v + gbase0 + q);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                int q = (threadIdx.x + it * 256) * 4;
-                if (q < s.cols) {
-                    int pp = q / C, c = q - pp * C;         // C % 4 == 0: the four share pp
-                    float gq[4] = {a4[it].x, a4[it].y, a4[it].z, a4[it].w};
-                    float mq[4] = {m4[it].x, m4[it].y, m4[it].z, m4[it].w};
-                    float vq[4] = {v4[it].x, v4[it].y, v4[it].z, v4[it].w};
-                    float pq[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float gi = fminf(fmaxf(gq[k] * gscale, -clip), clip);
-                        float pi = row[(c + k) * pitch + pp];
-                        gi += wd * pi;
-                        mq[k] = b1 * mq[k] + (1.f - b1) * gi;
-                        vq[k] = b2 * vq[k] + (1.f - b2) * gi * gi;
-                        pi -= step_size * mq[k] / (sqrtf(vq[k]) * inv_sqrt_bc2 + eps);
-                        row[(c + k) * pitch + pp] = pi;
-                        pq[k] = pi;
-                    }
-                    *reinterpret_cast<float4*>(m + gbase0 + q) = make_float4(mq[0], mq[1], mq[2], mq[3]);
-                    *reinterpret_cast<float4*>(v + gbase0 + q) = make_float4(vq[0], vq[1], vq[2], vq[3]);
-                    *reinterpret_cast<uint2*>(shadow + sbase0 + q) = make_uint2(pack2bf(pq[0], pq[1]), pack2bf(pq[2], pq[3]));
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                int i = (threadIdx.x + it * 256) * 4;
-                if (i < s.cols) {
-                    float e4[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        int c = (i + k) / P, pp = (i + k) - c * P;
-                        e4[k] = row[c * pitch + pp];
-                    }
-                    *reinterpret_cast<float4*>(prow + i) = make_float4(e4[0], e4[1], e4[2], e4[3]);
-                }
-            }
-            return;
-        }
-        for (int i = threadIdx.x; i < s.cols; i += 256) {
-            int c = i / P, pp = i - c * P;
-            row[c * pitch + pp] = prow[i];
-        }
-        __syncthreads();
-        long gbase = (long)s.start + (long)r * s.cols;
-        long sbase = (long)s.shadow_off + (long)r * s.shadow_ld;
-        for (int q = threadIdx.x; q < s.cols; q += 256) {   // q = pp * C + c (kernel order)
-            int pp = q / C, c = q - pp * C;
-            long i = gbase + q;
-            float gi = grad_at(x, ch.x, r * s.cols + q, g, i) * gscale;
-            gi = fminf(fmaxf(gi, -clip), clip);
-            float pi = row[c * pitch + pp];
-            gi += wd * pi;
-            float mi = b1 * m[i] + (1.f - b1) * gi;
-            float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-            pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
-            row[c * pitch + pp] = pi; m[i] = mi; v[i] = vi;
-            shadow[sbase + q] = f2bf(pi);
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < s.cols; i += 256) {
-            int c = i / P, pp = i - c * P;
-            prow[i] = row[c * pitch + pp];
-        }
-        return;
-    }
-    int end = min(ch.y + chunk_len(s), s.count);
-    if ((s.flags & 2) && x.slab != nullptr && x.slabinfo[ch.x].y > 0) {
-        // Slab-summed segment: 64 elements per workgroup, wave w adds slices w, w + 4, .. with 8 loads in
-        // flight per lane, the four partial sums meet in LDS.  (One thread per element walking all the
-        // slices -- 256 of them for conv1 at batch 128 -- was a chain of ~64 dependent memory round trips
-        // on 32 workgroups: it set the duration of the whole launch.)
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int e = ch.y + lane;
-        const bool ok = e < end;
-        const int4 sinfo = x.slabinfo[ch.x];
-        const float* q = x.slab + sinfo.x + (ok ? e : ch.y);
-        float acc[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-        int sl = wave;
-        for (; sl + 28 < sinfo.y; sl += 32) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += q[(long)(sl + 4 * u) * sinfo.z];
-        }
-        for (; sl < sinfo.y; sl += 4) acc[0] += q[(long)sl * sinfo.z];
-        row[wave * 64 + lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-        __syncthreads();
-        if (wave == 0 && ok) {
-            long si;
-            long ip = master_index(s, e, &si);
-            long i = (long)s.start + e;
-            float gi = (row[lane] + row[64 + lane]) + (row[128 + lane] + row[192 + lane]);
-            g[i] = gi;          // keep the flat gradient readable (tests, debugging)
-            gi = fminf(fmaxf(gi * gscale, -clip), clip);
-            float pi = p[ip];
-            gi += wd * pi;
-            float mi = b1 * m[i] + (1.f - b1) * gi;
-            float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-            pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
-            p[ip] = pi; m[i] = mi; v[i] = vi;
-            if (si >= 0) shadow[si] = f2bf(pi);
-        }
-        return;
-    }
-    for (int e = ch.y + threadIdx.x; e < end; e += 256) {
-        long si;
-        long ip = master_index(s, e, &si);
-        long i = (long)s.start + e;
-        float gi = grad_at(x, ch.x, e, g, i) * gscale;
-        gi = fminf(fmaxf(gi, -clip), clip);
-        float pi = p[ip];
-        gi += wd * pi;
-        float mi = b1 * m[i] + (1.f - b1) * gi;
-        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
-        p[ip] = pi; m[i] = mi; v[i] = vi;
-        if (si >= 0) shadow[si] = f2bf(pi);
-    }
+    adam_block(p, g, m, v, shadow, segs, chunks, nchunks, hyper, step, x, (int)blockIdx.x, row);
 }
 
 __global__ void tick_kernel(int* step, unsigned long long* counter) {

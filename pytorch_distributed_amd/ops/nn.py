@@ -293,6 +293,27 @@ def conv_wgrad_pair(dys, xs, gws, gbs, batch, geoms, O, ksplit, slice_strides, b
                           iarr[4], iarr[5], int(O), ss, bs, int(ksplit), _stream())
 
 
+def adam_with_wgrad_pair(dys, xs, gws, gbs, batch, geoms, O, ksplit, slice_strides, bslice_strides, adam, table):
+    """conv_wgrad_pair plus the optimizer workgroups of `table` (segments whose gradients are already final: the
+    fc tail) in one launch (csrc/gemm.hip:pda_adam_with_wgrad_pair).  adam: ops.optim.FlatAdam."""
+    import ctypes as _ct
+    L = _L()
+    if not getattr(L, "_pair_adam_ready", False):
+        L.pda_adam_with_wgrad_pair.argtypes = ([_vp] * 4 + [_ct.c_int] + [_vp] * 6 + [_ct.c_int, _vp, _vp, _ct.c_int] +
+                                               [_vp] * 7 + [_ct.c_int, _vp, _vp, _vp])
+        L.pda_adam_with_wgrad_pair.restype = None
+        L._pair_adam_ready = True
+    cols = list(zip(*geoms))
+    iarr = [(_ct.c_int * 2)(*[int(v) for v in col]) for col in cols]
+    ss = (_ct.c_long * 2)(*[int(v) for v in slice_strides])
+    bs = (_ct.c_long * 2)(*[int(v) for v in bslice_strides])
+    L.pda_adam_with_wgrad_pair(_arr(dys), _arr(xs), _arr(gws), _arr(gbs), int(batch), iarr[0], iarr[1], iarr[2],
+                               iarr[3], iarr[4], iarr[5], int(O), ss, bs, int(ksplit),
+                               _ptr(adam.p), _ptr(adam.g), _ptr(adam.m), _ptr(adam.v), _ptr(adam.shadow),
+                               _ptr(table.segs), _ptr(table.chunks), int(table.nchunks), _ptr(adam.hyper),
+                               _ptr(adam.step_dev), _stream())
+
+
 def conv_wgrad_u8(dy, frames, idx, gw, gb, batch, H, W, C, KH, KW, S, O, scale, ksplit=0, slice_stride=0,
                   bslice_stride=0):
     assert ksplit == 0 or slice_stride >= O * C * KH * KW
