@@ -117,11 +117,20 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
             // before the first use: the scalar loops below make ~13 dependent round trips per row, which kept
             // this launch at 3.4 TB/s.
             constexpr int IT = (OPT_ROW_LDS + 1023) / 1024;
-            float4 a4[IT], m4[IT], v4[IT];
+            float4 a4[IT], g4[IT], m4[IT], v4[IT];
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 int i = (threadIdx.x + it * 256) * 4;
                 if (i < s.cols) a4[it] = *reinterpret_cast<const float4*>(prow + i);
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {       // gradient / moments: kernel order, coalesced; in flight together
+                int q = (threadIdx.x + it * 256) * 4;   // with the master row (one memory round trip, not two)
+                if (q < s.cols) {
+                    g4[it] = *reinterpret_cast<const float4*>(g + gbase0 + q);
+                    m4[it] = *reinterpret_cast<const float4*>(m + gbase0 + q);
+                    v4[it] = *reinterpret_cast<const float4*>(v + gbase0 + q);
+                }
             }
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
@@ -135,22 +144,13 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
                     }
                 }
             }
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {       // gradient / moments: kernel order, coalesced
-                int q = (threadIdx.x + it * 256) * 4;
-                if (q < s.cols) {
-                    a4[it] = *reinterpret_cast<const float4*>(g + gbase0 + q);
-                    m4[it] = *reinterpret_cast<const float4*>(m + gbase0 + q);
-                    v4[it] = *reinterpret_cast<const float4*>(v + gbase0 + q);
-                }
-            }
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 int q = (threadIdx.x + it * 256) * 4;
                 if (q < s.cols) {
                     int pp = q / C, c = q - pp * C;         // C % 4 == 0: the four share pp
-                    float gq[4] = {a4[it].x, a4[it].y, a4[it].z, a4[it].w};
+                    float gq[4] = {g4[it].x, g4[it].y, g4[it].z, g4[it].w};
                     float mq[4] = {m4[it].x, m4[it].y, m4[it].z, m4[it].w};
                     float vq[4] = {v4[it].x, v4[it].y, v4[it].z, v4[it].w};
                     float pq[4];
