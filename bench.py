@@ -135,7 +135,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        # (host tensors under gloo: its device path stalls when the rehearsal's ranks share one GPU)
+        red_dev = device if getattr(comm, "backend", None) == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = core.loss_values().get("critic_loss", float("nan"))
@@ -145,7 +147,7 @@ def main():
         mine = core.flat_params().detach().clone()
         ref = mine.clone()
         comm.broadcast_(ref, src=0)
-        diff = (mine - ref).abs().max().reshape(1)
+        diff = (mine - ref).abs().max().reshape(1).to(red_dev)
         torch.distributed.all_reduce(diff, op=torch.distributed.ReduceOp.MAX)
         extra["dp_param_max_abs_diff_across_ranks"] = float(diff.item())
     if a.actor_bench and rank == 0 and native:

@@ -90,6 +90,19 @@ class TorchComm(SingleComm):
         self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
+    def _all_reduce(self, flat, op):
+        """dist.all_reduce; a GPU tensor under the gloo back-end (rehearsals of the multi-rank learner
+        on one card, tests) is staged through the host here: gloo's own device path stalls when the
+        ranks share a GPU (both ranks inside the second all-reduce of a step, measured on this pool),
+        and a host-side reduce is what that back-end does underneath anyway."""
+        if self.backend == "gloo" and flat.is_cuda:
+            host = flat.detach().to("cpu")      # waits for what is queued on the current stream
+            dist.all_reduce(host, op=op, group=self.group)
+            flat.copy_(host)
+            return flat
+        dist.all_reduce(flat, op=op, group=self.group)
+        return flat
+
     def all_reduce_mean_(self, flat, async_op=False):
         """In-place mean over ranks.  With async_op the reduce runs on a side
         stream after everything already queued on the current stream; call
@@ -97,10 +110,10 @@ class TorchComm(SingleComm):
         if self.comm_stream is not None and async_op:
             self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                self._all_reduce(flat, dist.ReduceOp.SUM)
                 flat.mul_(1.0 / self.world_size)
             return self.comm_stream
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        self._all_reduce(flat, dist.ReduceOp.SUM)
         flat.mul_(1.0 / self.world_size)
         return None
 
@@ -109,20 +122,24 @@ class TorchComm(SingleComm):
             torch.cuda.current_stream(self.device).wait_stream(handle)
 
     def all_reduce_sum_(self, flat):
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        return flat
+        return self._all_reduce(flat, dist.ReduceOp.SUM)
 
     def broadcast_(self, flat, src=0):
+        if self.backend == "gloo" and flat.is_cuda:
+            host = flat.detach().to("cpu")
+            dist.broadcast(host, src=src, group=self.group)
+            flat.copy_(host)
+            return flat
         dist.broadcast(flat, src=src, group=self.group)
         return flat
 
     def all_agree(self, flag):
         self._flag.fill_(1 if flag else 0)
-        dist.all_reduce(self._flag, op=dist.ReduceOp.MIN, group=self.group)
+        self._all_reduce(self._flag, dist.ReduceOp.MIN)
         return bool(self._flag.item())
 
     def barrier(self):
-        if self.device.type == "cuda":
+        if self.device.type == "cuda" and self.backend != "gloo":
             dist.barrier(group=self.group, device_ids=[self.device.index if self.device.index is not None else 0])
         else:
             dist.barrier(group=self.group)
