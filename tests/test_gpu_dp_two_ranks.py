@@ -1,0 +1,35 @@
+"""Two data-parallel learner ranks of the native (HIP) step program on ONE card.
+
+RCCL refuses two ranks on one device, so the rehearsal runs over gloo (host-staged all-reduces,
+parallel/comm.py) with both ranks on cuda:0: what it checks is the multi-rank step program itself --
+bucket order, split optimizer, per-rank replay shards and RNG streams -- by requiring the parameters
+of the two ranks to be identical after the run.  (Reference: num_learners > 1 is Hogwild on shared
+CUDA tensors, main.py:83-94 / dqn_learner.py:27-39; here it is synchronous data parallelism.)
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_two_rank_dp_bench_keeps_ranks_identical():
+    env = dict(os.environ)
+    env.pop("PDA_DP_GRAPH", None)
+    env["PDA_BENCH_FAULTHANDLER"] = "100"       # a stalled rank dumps its stack and exits
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29733", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "40", "--warmup", "5", "--backend", "gloo", "--share-gpu", "--replay", "4096"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=115)
+    assert out.returncode == 0, out.stderr.decode(errors="replace")[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                       # rank 0 prints the one JSON line
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 256
+    assert res["config"]["engine"] == "DqnNativeCore" and res["config"]["collectives"] == "gloo"
+    assert res["dp_param_max_abs_diff_across_ranks"] == 0.0
+    assert res["final_loss"] == res["final_loss"] and res["value"] > 0      # finite
