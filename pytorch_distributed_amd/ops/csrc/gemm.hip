@@ -239,7 +239,12 @@ PDA_EXPORT void pda_conv_wgrad_pair(const void* const* dy, const void* const* x,
         if (K > maxN) maxN = K;
         if (M > maxK) maxK = M;
     }
-    launch_gemm<64, 64, 2, 2>(a, 2, O, maxN, maxK, ksplit, stream);
+    static const bool xcd = std::getenv("PDA_XCD_ORDER") == nullptr || std::atoi(std::getenv("PDA_XCD_ORDER")) != 0;
+    if (!xcd) { launch_gemm<64, 64, 2, 2>(a, 2, O, maxN, maxK, ksplit, stream); return; }
+    int3 grid = plan_gemm<64, 64>(a, 2, O, maxN, maxK, ksplit);
+    int units = grid.y * grid.z;
+    hipLaunchKernelGGL((gemm_xcd_kernel<64, 64, 2, 2, GEMM_BK, SrcDenseT, SrcIm2colT, EpiWgrad>),
+                       dim3((units + 7) / 8 * 8 * grid.x), dim3(GEMM_THREADS), 0, stream, a, grid);
 }
 
 // The conv2 / conv3 weight-gradient pair and the optimizer update of the fc tail in ONE launch.  At batch 128 the
