@@ -554,13 +554,39 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs<SA, SB, EP>
 // For pairs of under-filled launches with no dependence on each other (fc1's data gradient: 196 workgroups, and
 // the two fc weight gradients) that would otherwise run back to back.  grid1 = (tiles, k-slices, groups) of the
 // first problem; the second is decoded the same way from the remaining indices.
+// XCD-aware order for un-split problems (grid.y == 1): workgroups go to the 8 XCDs round-robin by linear id; the
+// m-tiles of one column block (n-tile, group) -- which all read the same columns of the B operand -- are given ids
+// that are equal mod 8, so they share one XCD's L2.  Local id l -> (bx, bz); false = padding workgroup.
+__host__ __device__ inline int xcd_cols_blocks(int3 grid, int tiles_n) {
+    return (tiles_n * grid.z + 7) / 8 * 8 * (grid.x / tiles_n);
+}
+__device__ __forceinline__ bool xcd_cols_decode(int l, int3 grid, int tiles_n, int& bx, int& bz) {
+    const int tm = grid.x / tiles_n, x = l & 7, j = l >> 3;
+    const int unit = (j / tm) * 8 + x;
+    if (unit >= tiles_n * grid.z) return false;
+    bz = unit / tiles_n;
+    bx = (j % tm) * tiles_n + unit % tiles_n;
+    return true;
+}
+
 template <int BM1, int BN1, int WM1, int WN1, class SA1, class SB1, class EP1,
           int BM2, int BN2, int WM2, int WN2, class SA2, class SB2, class EP2, int BK = GEMM_BK>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_duo_kernel(GemmArgs<SA1, SB1, EP1> a1, int3 grid1,
-                                                                GemmArgs<SA2, SB2, EP2> a2, int3 grid2) {
+                                                                GemmArgs<SA2, SB2, EP2> a2, int3 grid2, int xcd) {
     constexpr int L1 = gemm_lds_elems<BM1, BN1, BK, SA1, SB1>(), L2 = gemm_lds_elems<BM2, BN2, BK, SA2, SB2>();
     __shared__ __attribute__((aligned(16))) bf16_t lds[L1 > L2 ? L1 : L2];
     int b = blockIdx.x;
+    if (xcd) {          // both problems un-split (grid.y == 1, checked by the launcher)
+        const int p1 = xcd_cols_blocks(grid1, a1.tiles_n);
+        int bx, bz;
+        if (b < p1) {
+            if (xcd_cols_decode(b, grid1, a1.tiles_n, bx, bz))
+                gemm_body<BM1, BN1, WM1, WN1, BK, SA1, SB1, EP1>(a1, bx, 0, bz, lds);
+        } else if (xcd_cols_decode(b - p1, grid2, a2.tiles_n, bx, bz)) {
+            gemm_body<BM2, BN2, WM2, WN2, BK, SA2, SB2, EP2>(a2, bx, 0, bz, lds);
+        }
+        return;
+    }
     const int n1 = grid1.x * grid1.y * grid1.z;
     if (b < n1) {
         gemm_body<BM1, BN1, WM1, WN1, BK, SA1, SB1, EP1>(a1, b % grid1.x, (b / grid1.x) % grid1.y, b / (grid1.x * grid1.y), lds);
