@@ -138,6 +138,36 @@ class TorchComm(SingleComm):
         self._all_reduce(self._flag, dist.ReduceOp.MIN)
         return bool(self._flag.item())
 
+    def verify_ranks(self):
+        """Proof that `world_size` DISTINCT ranks take part in this group's collectives: MIN / MAX / SUM
+        all-reduces of the rank id, and an all-gather of (rank, device index, device uuid hash).
+        Returns JSON-friendly facts (bench.py prints them; the launcher test asserts on them)."""
+        red = self.device if self.backend == "nccl" else torch.device("cpu")
+        me = torch.tensor([self.rank], dtype=torch.int64, device=red)
+        lo, hi, tot = me.clone(), me.clone(), me.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+        dev_index, uuid = -1, 0
+        if self.device.type == "cuda":
+            dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            props = torch.cuda.get_device_properties(dev_index)
+            ident = str(getattr(props, "uuid", "")) or "%s/%d" % (props.name, dev_index)
+            uuid = int.from_bytes(ident.encode()[-7:], "little") if ident else 0
+        mine = torch.tensor([self.rank, dev_index, uuid, os.getpid()], dtype=torch.int64, device=red)
+        rows = [torch.zeros_like(mine) for _ in range(self.world_size)]
+        dist.all_gather(rows, mine, group=self.group)
+        rows = [[int(v) for v in r.tolist()] for r in rows]
+        n = self.world_size
+        return {"rccl_ranks": dist.get_world_size(group=self.group), "collective_backend": self.backend,
+                "rank_id_min_max_sum": [int(lo.item()), int(hi.item()), int(tot.item())],
+                "ranks_distinct": (sorted(r[0] for r in rows) == list(range(n)) and int(lo.item()) == 0
+                                   and int(hi.item()) == n - 1 and int(tot.item()) == n * (n - 1) // 2
+                                   and len(set(r[3] for r in rows)) == n),
+                "rank_devices": [{"rank": r[0], "device_index": r[1], "device_uuid_hash": r[2], "pid": r[3]}
+                                 for r in rows],
+                "devices_distinct": len(set((r[1], r[2]) for r in rows)) == n}
+
     def barrier(self):
         if self.device.type == "cuda" and self.backend != "gloo":
             dist.barrier(group=self.group, device_ids=[self.device.index if self.device.index is not None else 0])

@@ -61,8 +61,14 @@ PRESETS = {
 }
 
 
+def _have_gpu():
+    # device_count() does not initialise the HIP runtime in the calling process (is_available() does): the
+    # launcher's parent builds Options and must stay GPU-free, because it starts every worker as a child
+    return torch.cuda.device_count() > 0
+
+
 def _default_device():
-    return "cuda" if torch.cuda.is_available() else "cpu"
+    return "cuda" if _have_gpu() else "cpu"
 
 
 def _parse_value(text):
@@ -128,7 +134,12 @@ class Params(object):
         self.native_nstep = True            # ring-fed memories: n-step assembly + record packing in C (K11)
         self.weight_sync = "auto"           # learner -> inference server weights: "shm" | "collective" (RCCL/gloo broadcast)
         self.actor_nice = 5                 # niceness added to actor processes (0 = leave alone)
-        self.compute = "auto"               # "auto" | "native" (HIP kernels, bf16 MFMA) | "torch" (fp32 eager)
+        self.compute = "auto"               # "auto" | "native" (HIP kernels, MFMA) | "torch" (fp32 eager)
+        # arithmetic of the native Nature-CNN engine.  "fp32": every MFMA product is a split-bf16 x3 product
+        # (a_hi*b_hi + a_lo*b_hi + a_hi*b_lo, fp32 accumulation; 16-bit significands, gradients within 1e-3 of an
+        # fp32 PyTorch step -- the reference learner is fp32, core/single_processes/dqn_learner.py:63-87);
+        # "bf16": plain bf16 operands (fastest; conv gradients within ~10 % of fp32)
+        self.precision = "fp32"
         self.param_sync_freq = 25           # learner publishes weights every this many learner steps
         self.supervise = True               # restart dead actors, stop everything if a learner dies
         self.inject_fault = None            # e.g. "actor:1@50" kills actor 1 at its 50th step (tests)
@@ -296,8 +307,8 @@ class Options(Params):
         mp = self.memory_params
         if "memory_params.enable_per" not in overrides:
             mp.enable_per = "per" in self.memory_type
-        if mp.replay_device == "cuda" and not torch.cuda.is_available():
+        if mp.replay_device == "cuda" and not _have_gpu():
             mp.replay_device = "cpu"
-        if self.device == "cuda" and not torch.cuda.is_available():
+        if self.device == "cuda" and not _have_gpu():
             self.device = "cpu"
         return self

@@ -21,9 +21,12 @@ def test_two_rank_dp_bench_keeps_ranks_identical():
     env = dict(os.environ)
     env.pop("PDA_DP_GRAPH", None)
     env["PDA_BENCH_FAULTHANDLER"] = "100"       # a stalled rank dumps its stack and exits
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29733", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "40", "--warmup", "5", "--backend", "gloo", "--share-gpu", "--replay", "4096"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # no torchrun: bench.py starts its two ranks itself (fresh children of a parent that never touches the GPU)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5",
+           "--backend", "gloo", "--share-gpu", "--replay", "4096", "--min-time", "0", "--precision", "bf16",
+           "--allreduce", "rccl", "--launch-timeout", "100"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=115)
     assert out.returncode == 0, out.stderr.decode(errors="replace")[-2000:]
     lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
@@ -32,4 +35,5 @@ def test_two_rank_dp_bench_keeps_ranks_identical():
     assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 256
     assert res["config"]["engine"] == "DqnNativeCore" and res["config"]["collectives"] == "gloo"
     assert res["dp_param_max_abs_diff_across_ranks"] == 0.0
+    assert res["rccl_ranks"] == 2 and res["ranks_distinct"] is True and res["rank_id_min_max_sum"] == [0, 1, 1]
     assert res["final_loss"] == res["final_loss"] and res["value"] > 0      # finite
