@@ -56,16 +56,25 @@ __device__ __forceinline__ uint4 mask16(uint4 v, bool ok) {
         uint2 lo = u8x4_to_bf16x4(ok ? v.x : 0u), hi = u8x4_to_bf16x4(ok ? v.y : 0u);        \
         return make_uint4(lo.x, lo.y, hi.x, hi.y);                                           \
     }
+// raw_at(ctx, k, lim, ok, off) issues the load `off` elements past the operand's base (the lo plane of a split
+// operand, SrcSplit below); raw() is the plain form.  bias_lim(): reduction indices below it count towards the
+// bias gradient (column sums of the A operand) -- everything, for a plain source.
+#define PDA_SOURCE_RAW                                                                       \
+    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const {       \
+        return raw_at(c, k, lim, ok, 0);                                                     \
+    }                                                                                        \
+    __device__ __forceinline__ int bias_lim() const { return 0x7fffffff; }
 struct SrcDenseK {      // element(row, k) = p[row*ld + k]; K-contiguous
     static constexpr bool kT = false;
     const bf16_t* p; long ld; int rows; int red;
     struct Ctx { const bf16_t* base; bool ok; };
     __device__ __forceinline__ Ctx prep(int row) const { return {p + (long)row * ld, row < rows}; }
     PDA_BF16_SOURCE_FINISH
-    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const {
+    __device__ __forceinline__ Raw raw_at(const Ctx& c, int k, int lim, bool& ok, long off) const {
         ok = c.ok && k < lim;
-        return *reinterpret_cast<const uint4*>(ok ? c.base + k : p);
+        return *reinterpret_cast<const uint4*>((ok ? c.base + k : p) + off);
     }
+    PDA_SOURCE_RAW
 };
 
 struct SrcDenseT {      // element(row, k) = p[k*ld + row]; row-contiguous
@@ -74,10 +83,11 @@ struct SrcDenseT {      // element(row, k) = p[k*ld + row]; row-contiguous
     struct Ctx { const bf16_t* base; bool ok; };
     __device__ __forceinline__ Ctx prep(int row0) const { return {p + row0, row0 < rows}; }
     PDA_BF16_SOURCE_FINISH
-    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const {
+    __device__ __forceinline__ Raw raw_at(const Ctx& c, int k, int lim, bool& ok, long off) const {
         ok = c.ok && k < lim;
-        return *reinterpret_cast<const uint4*>(ok ? c.base + (long)k * ld : p);
+        return *reinterpret_cast<const uint4*>((ok ? c.base + (long)k * ld : p) + off);
     }
+    PDA_SOURCE_RAW
 };
 
 // NHWC bf16 activations viewed as im2col rows: row m = (b, oy, ox), k = (ky, kx, c)
@@ -94,12 +104,13 @@ struct SrcIm2colK {
         return {p + (((long)b * g.H + oy * g.S) * g.W + ox * g.S) * g.C, m < rows};
     }
     PDA_BF16_SOURCE_FINISH
-    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const {
+    __device__ __forceinline__ Raw raw_at(const Ctx& c, int k, int lim, bool& ok, long poff) const {
         ok = c.ok && k < lim;
         int run = g.KW * g.C;
         int ky = k / run, off = k - ky * run;
-        return *reinterpret_cast<const uint4*>(ok ? c.base + (long)ky * g.W * g.C + off : p);
+        return *reinterpret_cast<const uint4*>((ok ? c.base + (long)ky * g.W * g.C + off : p) + poff);
     }
+    PDA_SOURCE_RAW
 };
 
 struct SrcIm2colT {     // rows = k-columns of the im2col matrix (8 consecutive), reduction = m
@@ -112,14 +123,15 @@ struct SrcIm2colT {     // rows = k-columns of the im2col matrix (8 consecutive)
         return {(long)ky * g.W * g.C + off, kc0 < rows};
     }
     PDA_BF16_SOURCE_FINISH
-    __device__ __forceinline__ Raw raw(const Ctx& c, int m, int lim, bool& ok) const {
+    __device__ __forceinline__ Raw raw_at(const Ctx& c, int m, int lim, bool& ok, long poff) const {
         ok = c.ok && m < lim;
         int ohw = g.OH * g.OW;
         int b = m / ohw, r = m - b * ohw;
         int oy = r / g.OW, ox = r - oy * g.OW;
         const bf16_t* base = p + (((long)b * g.H + oy * g.S) * g.W + ox * g.S) * g.C;
-        return *reinterpret_cast<const uint4*>(ok ? base + c.off : p);
+        return *reinterpret_cast<const uint4*>((ok ? base + c.off : p) + poff);
     }
+    PDA_SOURCE_RAW
 };
 
 // ---- conv data gradient as a gather (no dcol matrix, no col2im pass) ------------------------
@@ -142,13 +154,14 @@ struct SrcDgradDyK {    // A operand: element(m, k) = dy[b, iy2 - a, ix2 - b, o]
         return {p + (long)b * g.OH * g.OW * g.O, iy2, ix2, ok};
     }
     PDA_BF16_SOURCE_FINISH
-    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const {
+    __device__ __forceinline__ Raw raw_at(const Ctx& c, int k, int lim, bool& ok, long poff) const {
         int tap = k / g.O, o = k - tap * g.O;
         int a = tap / g.TW, bb = tap - a * g.TW;
         int oy = c.iy2 - a, ox = c.ix2 - bb;
         ok = c.ok && k < lim && oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW;
-        return *reinterpret_cast<const uint4*>(ok ? c.base + ((long)oy * g.OW + ox) * g.O + o : p);
+        return *reinterpret_cast<const uint4*>((ok ? c.base + ((long)oy * g.OW + ox) * g.O + o : p) + poff);
     }
+    PDA_SOURCE_RAW
 };
 
 struct SrcDgradWT {     // B operand: element(row = c, k = (a,b,o)) = w[o][(ky,kx,c)], 8 consecutive c per load
@@ -157,13 +170,14 @@ struct SrcDgradWT {     // B operand: element(row = c, k = (a,b,o)) = w[o][(ky,k
     struct Ctx { const bf16_t* base; bool ok; };
     __device__ __forceinline__ Ctx prep(int c0) const { return {p + c0, c0 < rows}; }
     PDA_BF16_SOURCE_FINISH
-    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const {
+    __device__ __forceinline__ Raw raw_at(const Ctx& c, int k, int lim, bool& ok, long poff) const {
         ok = c.ok && k < lim;
         int tap = k / g.O, o = k - tap * g.O;
         int a = tap / g.TW, bb = tap - a * g.TW;
         int ky = g.py + g.S * a, kx = g.px + g.S * bb;
-        return *reinterpret_cast<const uint4*>(ok ? c.base + ((long)o * g.KH * g.KW + ky * g.KW + kx) * g.C : p);
+        return *reinterpret_cast<const uint4*>((ok ? c.base + ((long)o * g.KH * g.KW + ky * g.KW + kx) * g.C : p) + poff);
     }
+    PDA_SOURCE_RAW
 };
 
 // uint8 planar frames (B rows of C*H*W bytes, gathered through idx when non-null):
@@ -182,7 +196,8 @@ struct SrcFrameU8K {
         return {p + f * frame_bytes + (long)(oy * g.S) * g.W + ox * g.S, ok};
     }
     PDA_U8_SOURCE_FINISH
-    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const {
+    PDA_SOURCE_RAW
+    __device__ __forceinline__ Raw raw_at(const Ctx& c, int k, int lim, bool& ok, long) const {
         ok = c.ok && k < lim;
         int khw = g.KH * g.KW;
         int ch = k / khw, r = k - ch * khw;
@@ -203,7 +218,8 @@ struct SrcFrameU8T {    // rows = (c, ky, kx0..kx0+7), reduction = m
         return {((long)ch * g.H + ky) * g.W, kc0 < rows};
     }
     PDA_U8_SOURCE_FINISH
-    __device__ __forceinline__ Raw raw(const Ctx& c, int m, int lim, bool& ok) const {
+    PDA_SOURCE_RAW
+    __device__ __forceinline__ Raw raw_at(const Ctx& c, int m, int lim, bool& ok, long) const {
         ok = c.ok && m < lim;
         int mm = ok ? m : 0;
         int ohw = g.OH * g.OW;
@@ -215,6 +231,44 @@ struct SrcFrameU8T {    // rows = (c, ky, kx0..kx0+7), reduction = m
     }
 };
 
+// ---- split-bf16 operands: fp32-equivalent products on the bf16 matrix cores ---------------------------
+// A logical fp32 tensor x is kept as two bf16 planes, hi = bf16(x) at the source's base and lo = bf16(x - hi)
+// `plane` elements further on (16 significand bits together).  A product over a reduction of length red1 then
+// runs as ONE reduction of length NT * red1 in which operand copy t reads the lo plane iff bit t of LOMASK is set:
+//     A = (hi, lo, hi), B = (hi, hi, lo):   sum a_hi b_hi + a_lo b_hi + a_hi b_lo     (NT = 3; the a_lo b_lo term,
+//                                            2^-18 relative, is dropped; accumulation is the MFMA's fp32)
+//     one operand exact in bf16 (uint8 frames): (x, x) against (hi, lo)               (NT = 2)
+// so every kernel of the family serves the fp32-precision learner unchanged.  Needs red1 % 8 == 0 for
+// K-contiguous sources (a 16-byte load must not straddle two copies).
+template <class S, int NT, int LOMASK>
+struct SrcSplit {
+    static constexpr bool kT = S::kT;
+    S s; long plane; int red1;
+    typedef typename S::Ctx Ctx;
+    typedef typename S::Raw Raw;
+    __device__ __forceinline__ Ctx prep(int row) const { return s.prep(row); }
+    __device__ __forceinline__ static uint4 finish(Raw v, bool ok) { return S::finish(v, ok); }
+    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const {
+        int t = (k >= red1 ? 1 : 0) + ((NT > 2 && k >= 2 * red1) ? 1 : 0);
+        int kk = k - t * red1;
+        bool lo = (LOMASK >> t) & 1;
+        return s.raw_at(c, kk, (k < lim && kk < red1) ? red1 : 0, ok, lo ? plane : 0);
+    }
+    // column sums of a split A operand = sum over its (hi, lo) copies, which are always the first two
+    __device__ __forceinline__ int bias_lim() const { return 2 * red1; }
+};
+#define SPLIT_A3(S) SrcSplit<S, 3, 2>      /* (hi, lo, hi) */
+#define SPLIT_B3(S) SrcSplit<S, 3, 4>      /* (hi, hi, lo) */
+#define SPLIT_X2(S) SrcSplit<S, 2, 0>      /* exact operand, twice */
+#define SPLIT_HL2(S) SrcSplit<S, 2, 2>     /* (hi, lo) against an exact operand */
+
+// hi / lo planes of an fp32 value (lo written `plane` elements after hi; plane == 0: plain bf16 output)
+__device__ __forceinline__ void store_split(bf16_t* dst, long plane, float x) {
+    bf16_t h = f2bf(x);
+    *dst = h;
+    if (plane) dst[plane] = f2bf(x - bf2f(h));
+}
+
 // ----------------------------------------------------------------------------
 // epilogues: operator()(m, n, v) receives rows m..m+3 of column n
 // ----------------------------------------------------------------------------
@@ -225,7 +279,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 struct EpiBiasAct {     // out = act(acc*scale + bias[n]) -> bf16 (and/or fp32) row-major
-    bf16_t* out; float* out32; const float* bias; float scale; int act; long ld; long ld32;
+    bf16_t* out; float* out32; const float* bias; float scale; int act; long ld; long ld32; long plane;
     static constexpr bool kBiasGrad = false;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N) const {
         if (n >= N) return;
@@ -234,7 +288,7 @@ struct EpiBiasAct {     // out = act(acc*scale + bias[n]) -> bf16 (and/or fp32) 
         for (int r = 0; r < 4; ++r) {
             if (m + r < M) {
                 float x = apply_act(v[r] * scale + b, act);
-                if (out) out[(long)(m + r) * ld + n] = f2bf(x);
+                if (out) store_split(out + (long)(m + r) * ld + n, plane, x);
                 if (out32) out32[(long)(m + r) * ld32 + n] = x;
             }
         }
@@ -255,7 +309,7 @@ struct EpiAtomicF32 {   // split-K partial sums: atomicAdd acc into fp32 out[m*l
 };
 
 struct EpiMaskBf16 {    // dgrad: out = acc * act'(y[m][n]) -> bf16 ; y is the forward output
-    bf16_t* out; const bf16_t* y; int act; long ld; long ldy;
+    bf16_t* out; const bf16_t* y; int act; long ld; long ldy; long plane;
     static constexpr bool kBiasGrad = false;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N) const {
         if (n >= N) return;
@@ -267,7 +321,7 @@ struct EpiMaskBf16 {    // dgrad: out = acc * act'(y[m][n]) -> bf16 ; y is the f
                     float yy = bf2f(y[(long)(m + r) * ldy + n]);
                     g = (act == ACT_RELU) ? (yy > 0.f ? g : 0.f) : g * (1.f - yy * yy);
                 }
-                out[(long)(m + r) * ld + n] = f2bf(g);
+                store_split(out + (long)(m + r) * ld + n, plane, g);
             }
         }
     }
@@ -276,7 +330,7 @@ struct EpiMaskBf16 {    // dgrad: out = acc * act'(y[m][n]) -> bf16 ; y is the f
 
 // conv dgrad (gather form): row m of a parity class -> NHWC pixel row; out = acc * act'(y[pixel][n])
 struct EpiDgradScatter {
-    bf16_t* out; const bf16_t* y; int act; DgradGeom g;
+    bf16_t* out; const bf16_t* y; int act; DgradGeom g; long plane;
     static constexpr bool kBiasGrad = false;
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N) const {
         if (n >= N) return;
@@ -293,7 +347,7 @@ struct EpiDgradScatter {
                     float yy = bf2f(y[pix * g.C + n]);
                     gr = (act == ACT_RELU) ? (yy > 0.f ? gr : 0.f) : gr * (1.f - yy * yy);
                 }
-                out[pix * g.C + n] = f2bf(gr);
+                store_split(out + pix * g.C + n, plane, gr);
             }
         }
     }
@@ -476,9 +530,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<SA, SB, EP>& args, int 
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const bool do_bias = EP::kBiasGrad && tile_n == 0 && wn == 0;
-    bf16x8 ones;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+    const int bias_lim = G.a.bias_lim();        // INT_MAX for plain operands: `ones` below folds to a constant
 
     // The loads of k-tiles t+1 .. t+GEMM_PF are in flight while tile t is multiplied: at batch 128 these
     // launches are a few hundred blocks of 8-16 k-tiles, i.e. bound by memory latency, not by MFMA or
@@ -495,6 +547,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<SA, SB, EP>& args, int 
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 fa[FM], fb[FN];
+            bf16x8 ones;        // B fragment of the bias column sums: k = kk + 32 ks + 8 (lane >> 4) + j
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                ones[j] = (kk + ks * 32 + 8 * (lane >> 4) + j < bias_lim) ? (__bf16)1.0f : (__bf16)0.0f;
 #pragma unroll
             for (int i = 0; i < FM; ++i) fa[i] = read_frag<TA, BM, BK>(la, wm * (BM / WM) + i * 16, ks, lane);
 #pragma unroll

@@ -36,7 +36,15 @@ struct AdamExtras {
     const float* slab; const int4* slabinfo;        // per segment (slab_off, nslices, slice_stride, -)
     int* next_idx; float* next_w; int next_B; const int* size; unsigned long long seed;
     const unsigned long long* counter;
+    long shadow_plane;      // fp32-precision engines: the shadow's lo plane (bf16(w - bf16(w))) lies this many
+                            // elements after the hi plane; 0 = plain bf16 shadow
 };
+
+__device__ __forceinline__ void put_shadow(bf16_t* shadow, long si, float w, long plane) {
+    bf16_t h = f2bf(w);
+    shadow[si] = h;
+    if (plane) shadow[si + plane] = f2bf(w - bf2f(h));
+}
 
 #define OPT_CHUNK 2048      // elements per block (flat chunks)
 #define OPT_ROW_LDS 4352    // floats of LDS for one weight row in the transposition path (row pitch padded to odd)
@@ -167,7 +175,14 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
                     }
                     *reinterpret_cast<float4*>(m + gbase0 + q) = make_float4(mq[0], mq[1], mq[2], mq[3]);
                     *reinterpret_cast<float4*>(v + gbase0 + q) = make_float4(vq[0], vq[1], vq[2], vq[3]);
-                    *reinterpret_cast<uint2*>(shadow + sbase0 + q) = make_uint2(pack2bf(pq[0], pq[1]), pack2bf(pq[2], pq[3]));
+                    const uint2 hi2 = make_uint2(pack2bf(pq[0], pq[1]), pack2bf(pq[2], pq[3]));
+                    *reinterpret_cast<uint2*>(shadow + sbase0 + q) = hi2;
+                    if (x.shadow_plane) {
+                        const float r0 = pq[0] - bf2f((bf16_t)(hi2.x & 0xffffu)), r1 = pq[1] - bf2f((bf16_t)(hi2.x >> 16));
+                        const float r2 = pq[2] - bf2f((bf16_t)(hi2.y & 0xffffu)), r3 = pq[3] - bf2f((bf16_t)(hi2.y >> 16));
+                        *reinterpret_cast<uint2*>(shadow + x.shadow_plane + sbase0 + q) =
+                            make_uint2(pack2bf(r0, r1), pack2bf(r2, r3));
+                    }
                 }
             }
             __syncthreads();
@@ -204,7 +219,7 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
             float vi = b2 * v[i] + (1.f - b2) * gi * gi;
             pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
             row[c * pitch + pp] = pi; m[i] = mi; v[i] = vi;
-            shadow[sbase + q] = f2bf(pi);
+            put_shadow(shadow, sbase + q, pi, x.shadow_plane);
         }
         __syncthreads();
         for (int i = threadIdx.x; i < s.cols; i += 256) {
@@ -248,7 +263,7 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
             float vi = b2 * v[i] + (1.f - b2) * gi * gi;
             pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
             p[ip] = pi; m[i] = mi; v[i] = vi;
-            if (si >= 0) shadow[si] = f2bf(pi);
+            if (si >= 0) put_shadow(shadow, si, pi, x.shadow_plane);
         }
         return;
     }
@@ -264,6 +279,6 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
         float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
         p[ip] = pi; m[i] = mi; v[i] = vi;
-        if (si >= 0) shadow[si] = f2bf(pi);
+        if (si >= 0) put_shadow(shadow, si, pi, x.shadow_plane);
     }
 }

@@ -26,6 +26,8 @@ struct DqnHeadArgs {
     float* leaf_sum; float* leaf_min; float prio_eps, prio_alpha;
     int B, HID, A;
     unsigned long long* rng_counter; int* opt_step;     // bumped here (nobody reads them in this launch)
+    // fp32-precision learner: element offsets to the lo planes of the split-bf16 outputs (0: plain bf16 outputs)
+    long h1_plane, dh1_plane, dq_plane;
 };
 
 template <int HID>
@@ -125,8 +127,23 @@ __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
     uint32_t* dout = reinterpret_cast<uint32_t*>(p.dh1 + row);
 #pragma unroll
     for (int j = 0; j < PER / 2; ++j) { ho[j] = hw[j]; dout[j] = dw[j]; }
+    if (p.h1_plane) {       // residuals of the two rows: x - bf16(x), itself rounded to bf16
+        uint32_t* hl = reinterpret_cast<uint32_t*>(p.h1_on0 + p.h1_plane + row);
+        uint32_t* dl = reinterpret_cast<uint32_t*>(p.dh1 + p.dh1_plane + row);
+#pragma unroll
+        for (int j = 0; j < PER; j += 2) {
+            float d0 = h0[j] > 0.f ? dqa * wa[j] : 0.f, d1 = h0[j + 1] > 0.f ? dqa * wa[j + 1] : 0.f;
+            hl[j / 2] = pack2bf(h0[j] - bf2f((bf16_t)(hw[j / 2] & 0xffffu)), h0[j + 1] - bf2f((bf16_t)(hw[j / 2] >> 16)));
+            dl[j / 2] = pack2bf(d0 - bf2f((bf16_t)(dw[j / 2] & 0xffffu)), d1 - bf2f((bf16_t)(dw[j / 2] >> 16)));
+        }
+    }
 
-    if (lane < p.dq_ld) p.dq[(long)b * p.dq_ld + lane] = f2bf(lane == act ? dqa : 0.f);
+    if (lane < p.dq_ld) {
+        const float dv = lane == act ? dqa : 0.f;
+        const bf16_t dh = f2bf(dv);
+        p.dq[(long)b * p.dq_ld + lane] = dh;
+        if (p.dq_plane) p.dq[p.dq_plane + (long)b * p.dq_ld + lane] = f2bf(dv - bf2f(dh));
+    }
     if (lane < p.A && p.q_out) p.q_out[(long)b * p.A + lane] = myq0;
     if (lane == 0) {
         if (p.td_out) p.td_out[b] = td;
@@ -286,7 +303,7 @@ PDA_EXPORT void pda_adam_x(void* p, void* g, void* m, void* v, void* shadow, con
 // tgt = (1 - tau) tgt + tau src (tau >= 1: hard copy) on fp32 masters, with the target's shadow weights
 __global__ __launch_bounds__(256) void polyak_kernel(float* tgt, const float* src,
                                                      bf16_t* __restrict__ shadow, const SegEntry* __restrict__ segs,
-                                                     const int2* __restrict__ chunks, float tau) {
+                                                     const int2* __restrict__ chunks, float tau, long shadow_plane) {
     int2 ch = chunks[blockIdx.x];
     SegEntry s = segs[ch.x];
     int end = min(ch.y + chunk_len(s), s.count);
@@ -296,14 +313,14 @@ __global__ __launch_bounds__(256) void polyak_kernel(float* tgt, const float* sr
         float t = tgt[i] + tau * (src[i] - tgt[i]);
         if (tau >= 1.f) t = src[i];
         tgt[i] = t;
-        if (shadow && si >= 0) shadow[si] = f2bf(t);
+        if (shadow && si >= 0) put_shadow(shadow, si, t, shadow_plane);
     }
 }
 
 PDA_EXPORT void pda_polyak(void* tgt, const void* src, void* shadow, const void* segs, const void* chunks,
-                           int nchunks, float tau, hipStream_t stream) {
+                           int nchunks, float tau, long shadow_plane, hipStream_t stream) {
     hipLaunchKernelGGL(polyak_kernel, dim3(nchunks), dim3(256), 0, stream, (float*)tgt, (const float*)src,
-                       (bf16_t*)shadow, (const SegEntry*)segs, (const int2*)chunks, tau);
+                       (bf16_t*)shadow, (const SegEntry*)segs, (const int2*)chunks, tau, shadow_plane);
 }
 
 // plain multi-tensor Polyak over a flat fp32 buffer (no shadow): used by utils.helpers

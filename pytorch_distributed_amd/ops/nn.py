@@ -20,6 +20,7 @@ from . import lib
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 BF16 = torch.bfloat16
+GEMM_MAX_GROUPS = 4     # csrc/gemm.h: problem groups per launch
 
 _vp = ctypes.c_void_p
 
@@ -383,3 +384,161 @@ def nhwc(x):
 
 def from_nhwc(x, B, H, W, C):
     return x.float().reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+
+
+# ---- fp32-precision ("x3") family: split-bf16 operands, csrc/gemm_x3.hip ------------------------------------
+class Planes(object):
+    """A logical fp32 tensor kept as two bf16 planes: hi = bf16(x) in full[0], lo = bf16(x - hi) in full[1]
+    (16 significand bits together).  `plane` = elements from hi to lo, as the kernels take it."""
+
+    def __init__(self, *shape, device=None, split=True):
+        self.full = torch.zeros((2 if split else 1,) + tuple(shape), dtype=BF16, device=device)
+        self.hi = self.full[0]
+        self.plane = int(self.full.stride(0)) if split else 0
+
+    @classmethod
+    def from_float(cls, x):
+        """Split an fp32 tensor (tests, weight packing)."""
+        out = cls(*x.shape, device=x.device)
+        hi = x.to(BF16)
+        out.full[0].copy_(hi)
+        out.full[1].copy_((x - hi.float()).to(BF16))
+        return out
+
+    def data_ptr(self):
+        return self.hi.data_ptr()
+
+    def value(self):
+        """fp32 value the planes stand for."""
+        if self.full.shape[0] == 1:
+            return self.hi.float()
+        return self.full[0].float() + self.full[1].float()
+
+    def zero_(self):
+        self.full.zero_()
+        return self
+
+
+def _plane(t):
+    return int(getattr(t, "plane", 0))
+
+
+_x3_ready = False
+
+
+def _X():
+    global _x3_ready
+    L = _L()
+    if not _x3_ready:
+        c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
+        L.pda_x3_conv_fwd_u8.argtypes = [_vp] * 3 + [c_long, _vp, _vp, c_long] + [c_int] * 9 + [c_float, c_int, _vp]
+        L.pda_x3_conv_fwd.argtypes = [_vp, c_long, _vp, c_long, _vp, _vp, c_long] + [c_int] * 10 + [_vp]
+        L.pda_x3_linear_fwd.argtypes = [_vp, c_long, _vp, c_long, _vp] + [c_int] * 4 + [c_long] * 3 + [c_int, _vp]
+        L.pda_x3_linear_dgrad.argtypes = ([_vp, c_long, _vp, c_long, _vp, _vp, c_long] + [c_int] * 3 + [c_long] * 4 +
+                                          [c_int, _vp])
+        L.pda_x3_conv_dgrad.argtypes = [_vp, c_long, _vp, c_long, _vp, _vp, c_long] + [c_int] * 9 + [_vp]
+        L.pda_x3_linear_wgrad2.argtypes = [_vp] * 6 + [c_int, c_int] + [_vp] * 5 + [_vp]
+        L.pda_x3_fc_backward_duo.argtypes = ([_vp, c_long, _vp, c_long, _vp, _vp, c_long] + [c_int] * 3 + [c_long] * 4 +
+                                             [c_int] + [_vp] * 6 + [c_int] + [_vp] * 5 + [_vp])
+        L.pda_x3_conv_wgrad.argtypes = [_vp] * 6 + [c_int, c_int] + [_vp] * 6 + [c_int, _vp, _vp, c_int, _vp]
+        L.pda_x3_conv_wgrad_u8.argtypes = ([_vp, c_long, _vp, _vp, _vp, _vp] + [c_int] * 8 +
+                                           [c_float, c_long, c_long, c_int, _vp])
+        for name in ("pda_x3_conv_fwd_u8", "pda_x3_conv_fwd", "pda_x3_linear_fwd", "pda_x3_linear_dgrad",
+                     "pda_x3_conv_dgrad", "pda_x3_linear_wgrad2", "pda_x3_fc_backward_duo", "pda_x3_conv_wgrad",
+                     "pda_x3_conv_wgrad_u8"):
+            getattr(L, name).restype = None
+        _x3_ready = True
+    return L
+
+
+def _same_plane(ts):
+    planes = {_plane(t) for t in ts if t is not None}
+    assert len(planes) == 1, "problem groups of one launch share one plane offset"
+    return planes.pop()
+
+
+def _longs(vals):
+    return (ctypes.c_long * len(vals))(*[int(v) for v in vals])
+
+
+def _ints(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def x3_conv_fwd_u8(frames, idx, w, bias, out, batch, H, W, C, KH, KW, S, O, scale, act=ACT_RELU):
+    """conv_fwd_u8 with split weights (Planes) and split outputs; frames are exact."""
+    assert KW == 8 and len(frames) <= GEMM_MAX_GROUPS and (C * KH * KW) % 8 == 0
+    _X().pda_x3_conv_fwd_u8(_arr(frames), _arr(idx), _arr(w), _same_plane(w), _arr(bias), _arr(out), _same_plane(out),
+                            len(frames), batch, H, W, C, KH, KW, S, O, float(scale), act, _stream())
+
+
+def x3_conv_fwd(x, w, bias, out, batch, H, W, C, KH, KW, S, O, act=ACT_RELU):
+    assert C % 8 == 0 and len(x) <= GEMM_MAX_GROUPS
+    _X().pda_x3_conv_fwd(_arr(x), _same_plane(x), _arr(w), _same_plane(w), _arr(bias), _arr(out), _same_plane(out),
+                         len(x), batch, H, W, C, KH, KW, S, O, act, _stream())
+
+
+def x3_linear_fwd(x, w, out32, M, N, K, ldx, ldw, ldo32, ksplit=0):
+    """Split-K partial sums atomically added into the fp32 out32 (pre-zeroed); ksplit counts the 3 K reduction."""
+    assert K % 8 == 0 and ldx % 8 == 0 and ldw % 8 == 0 and len(x) <= GEMM_MAX_GROUPS
+    _X().pda_x3_linear_fwd(_arr(x), _same_plane(x), _arr(w), _same_plane(w), _arr(out32), len(x), M, N, K, ldx, ldw,
+                           ldo32, int(ksplit), _stream())
+
+
+def x3_linear_dgrad(dy, w, y, dx, M, Nout, Kin, lddy, ldw, ldy, lddx, act=ACT_NONE):
+    assert Nout % 8 == 0 and lddy % 8 == 0 and ldw % 8 == 0
+    _X().pda_x3_linear_dgrad(_ptr(dy), _plane(dy), _ptr(w), _plane(w), _ptr(y), _ptr(dx), _plane(dx), M, Nout, Kin,
+                             lddy, ldw, ldy, lddx, act, _stream())
+
+
+def x3_conv_dgrad(dy, w, yin, dx, batch, H, W, C, KH, KW, S, O, act=ACT_RELU):
+    assert S in (1, 2) and KH % S == 0 and KW % S == 0 and H % S == 0 and W % S == 0 and C % 8 == 0 and O % 8 == 0
+    _X().pda_x3_conv_dgrad(_ptr(dy), _plane(dy), _ptr(w), _plane(w), _ptr(yin), _ptr(dx), _plane(dx), batch, H, W, C,
+                           KH, KW, S, O, act, _stream())
+
+
+class X3LinearWgradPair(object):
+    """LinearWgradPair on split operands.  jobs: [(dy, x, gw, gb, Nout, Kin, lddy, ldx, ldg)] x 2 (dy, x: Planes)."""
+
+    def __init__(self, jobs, B):
+        assert len(jobs) == 2
+        self.keep, self.B = jobs, int(B)
+        self.dy = (_vp * 2)(*[j[0].data_ptr() for j in jobs])
+        self.dyp = _longs([_plane(j[0]) for j in jobs])
+        self.x = (_vp * 2)(*[j[1].data_ptr() for j in jobs])
+        self.xp = _longs([_plane(j[1]) for j in jobs])
+        self.gw = (_vp * 2)(*[j[2].data_ptr() for j in jobs])
+        self.gb = (_vp * 2)(*[j[3].data_ptr() for j in jobs])
+        self.nout, self.kin = _ints([j[4] for j in jobs]), _ints([j[5] for j in jobs])
+        self.lddy, self.ldx, self.ldg = (_longs([j[i] for j in jobs]) for i in (6, 7, 8))
+        for j in jobs:
+            assert j[6] % 8 == 0 and j[7] % 8 == 0
+
+    def run(self):
+        _X().pda_x3_linear_wgrad2(self.dy, self.dyp, self.x, self.xp, self.gw, self.gb, 2, self.B, self.nout,
+                                  self.kin, self.lddy, self.ldx, self.ldg, _stream())
+
+    def run_with_dgrad(self, dy, w, y, dx, M, Nout, Kin, lddy, ldw, ldy, lddx, act=ACT_NONE):
+        assert Nout % 8 == 0 and lddy % 8 == 0 and ldw % 8 == 0
+        _X().pda_x3_fc_backward_duo(_ptr(dy), _plane(dy), _ptr(w), _plane(w), _ptr(y), _ptr(dx), _plane(dx), M, Nout,
+                                    Kin, lddy, ldw, ldy, lddx, act, self.dy, self.dyp, self.x, self.xp, self.gw,
+                                    self.gb, self.B, self.nout, self.kin, self.lddy, self.ldx, self.ldg, _stream())
+
+
+def x3_conv_wgrad(dys, xs, gws, gbs, batch, geoms, O, ksplit, slice_strides, bslice_strides):
+    """One or two conv weight gradients (split operands) in one launch; the reduction is 3 * batch * OH * OW and
+    `ksplit` counts that extended reduction.  geoms: [(H, W, C, KH, KW, S)]."""
+    n = len(dys)
+    cols = list(zip(*geoms))
+    iarr = [_ints(col) for col in cols]
+    _X().pda_x3_conv_wgrad(_arr(dys), _longs([_plane(t) for t in dys]), _arr(xs), _longs([_plane(t) for t in xs]),
+                           _arr(gws), _arr(gbs), n, int(batch), iarr[0], iarr[1], iarr[2], iarr[3], iarr[4], iarr[5],
+                           int(O), _longs(slice_strides), _longs(bslice_strides), int(ksplit), _stream())
+
+
+def x3_conv_wgrad_u8(dy, frames, idx, gw, gb, batch, H, W, C, KH, KW, S, O, scale, ksplit=0, slice_stride=0,
+                     bslice_stride=0):
+    """conv1 weight gradient: dy split, frames exact; reduction 2 * batch * OH * OW."""
+    assert ksplit == 0 or slice_stride >= O * C * KH * KW
+    _X().pda_x3_conv_wgrad_u8(_ptr(dy), _plane(dy), _ptr(frames), _ptr(idx), _ptr(gw), _ptr(gb), batch, H, W, C, KH,
+                              KW, S, O, float(scale), slice_stride, bslice_stride, int(ksplit), _stream())

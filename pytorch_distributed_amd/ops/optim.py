@@ -66,14 +66,21 @@ def plain_table(numel, device):
 
 class AdamExtras(ctypes.Structure):     # mirrors AdamExtras in csrc/rl_kernels.hip
     _fields_ = [("slab", _vp), ("slabinfo", _vp), ("next_idx", _vp), ("next_w", _vp), ("next_B", ctypes.c_int),
-                ("size", _vp), ("seed", ctypes.c_ulonglong), ("counter", _vp)]
+                ("size", _vp), ("seed", ctypes.c_ulonglong), ("counter", _vp), ("shadow_plane", ctypes.c_long)]
 
 
 class FlatAdam(object):
     def __init__(self, flat_params, flat_grads, table, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 clip=np.inf, grad_scale=1.0, shadow=None):
+                 clip=np.inf, grad_scale=1.0, shadow=None, shadow_plane=0):
+        """shadow_plane: element offset from the shadow's hi plane to its lo plane (fp32-precision engines keep
+        split-bf16 shadow weights); 0 = plain bf16 shadow."""
         dev = flat_params.device
         self.p, self.g, self.table, self.shadow = flat_params, flat_grads, table, shadow
+        self.shadow_plane = int(shadow_plane)
+        self._plane_extras = None
+        if self.shadow_plane:
+            self._plane_extras = AdamExtras()
+            self._plane_extras.shadow_plane = self.shadow_plane
         self.m = torch.zeros_like(flat_params)
         self.v = torch.zeros_like(flat_params)
         clip = float(clip) if np.isfinite(clip) else 3.0e38
@@ -101,6 +108,10 @@ class FlatAdam(object):
         t = table if table is not None else self.table
         if t.nchunks == 0:
             return
+        if extras is None:
+            extras = self._plane_extras
+        elif self.shadow_plane:
+            extras.shadow_plane = self.shadow_plane
         if extras is not None:      # slab reduction and/or next-step sampler folded into this launch
             lib().pda_adam_x(_p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.shadow), _p(t.segs),
                              _p(t.chunks), t.nchunks, _p(self.hyper), _p(self.step_dev), ctypes.byref(extras),
@@ -114,9 +125,9 @@ class FlatAdam(object):
         self.hyper[6] = float(scale)
 
 
-def polyak_(tgt_flat, src_flat, tau, table=None, shadow=None):
+def polyak_(tgt_flat, src_flat, tau, table=None, shadow=None, shadow_plane=0):
     """tgt = (1-tau) tgt + tau src over flat fp32 buffers; tau >= 1 is a hard copy.
-    With a table + shadow the target's bf16 shadow weights are re-emitted too."""
+    With a table + shadow the target's bf16 shadow weights are re-emitted too (shadow_plane: see FlatAdam)."""
     L = lib()
     if table is None:
         L.pda_polyak_flat.argtypes = [_vp, _vp, ctypes.c_long, ctypes.c_float, _vp]
@@ -126,10 +137,10 @@ def polyak_(tgt_flat, src_flat, tau, table=None, shadow=None):
         else:
             L.pda_polyak_flat(_p(tgt_flat), _p(src_flat), int(tgt_flat.numel()), float(tau), _stream())
         return
-    L.pda_polyak.argtypes = [_vp] * 5 + [ctypes.c_int, ctypes.c_float, _vp]
+    L.pda_polyak.argtypes = [_vp] * 5 + [ctypes.c_int, ctypes.c_float, ctypes.c_long, _vp]
     L.pda_polyak.restype = None
     L.pda_polyak(_p(tgt_flat), _p(src_flat), _p(shadow), _p(table.segs), _p(table.chunks), table.nchunks,
-                 float(tau), _stream())
+                 float(tau), int(shadow_plane), _stream())
 
 
 def polyak_params_(dst_params, src_params, tau):
