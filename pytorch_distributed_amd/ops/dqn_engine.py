@@ -40,7 +40,7 @@ HID_SUPPORTED = (256, 512)
 
 
 def _p(t):
-    return t.data_ptr() if t is not None else 0
+    return t.data_ptr() if t is not None else 0     # (tensors and nn.Planes / _PlaneView alike)
 
 
 def _stream():
@@ -58,7 +58,8 @@ class _HeadArgs(ctypes.Structure):     # mirrors DqnHeadArgs in csrc/rl_kernels.
                 ("q_out", _vp), ("td_out", _vp), ("loss_sum", _vp),
                 ("leaf_sum", _vp), ("leaf_min", _vp), ("prio_eps", ctypes.c_float), ("prio_alpha", ctypes.c_float),
                 ("B", ctypes.c_int), ("HID", ctypes.c_int), ("A", ctypes.c_int),
-                ("rng_counter", _vp), ("opt_step", _vp)]
+                ("rng_counter", _vp), ("opt_step", _vp),
+                ("h1_plane", ctypes.c_long), ("dh1_plane", ctypes.c_long), ("dq_plane", ctypes.c_long)]
 
 
 class _ActArgs(ctypes.Structure):      # mirrors ActHeadArgs
@@ -128,21 +129,38 @@ class CnnGeometry(object):
             raise ValueError("unsupported head shape")
 
 
+class _PlaneView(object):
+    """hi-plane tensor view + element offset of the matching lo plane (what nn.x3_* take as an operand)."""
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo = hi, lo
+        self.plane = (lo.data_ptr() - hi.data_ptr()) // hi.element_size()
+
+    def data_ptr(self):
+        return self.hi.data_ptr()
+
+    def value(self):
+        return self.hi.float() + self.lo.float()
+
+
 class CnnWeights(object):
     """Views of one network's flat fp32 parameters + its bf16 shadow weights in
     kernel layout (conv: [O][(ky,kx,c)], conv1: [O][(c,ky,kx)], fc1: [N][(p,c)])."""
 
     ORDER = ("critic.0.0", "critic.0.2", "critic.0.4", "critic.1.0", "critic.1.2")
 
-    def __init__(self, model, geom, with_grad):
+    def __init__(self, model, geom, with_grad, split=False):
+        """split: the shadow keeps a second plane with the bf16 residuals w - bf16(w) (fp32-precision engine)."""
         self.model, self.g = model, geom
+        self.split = bool(split)
         self.flat = model.flatten_(with_grad=with_grad)
         dev = self.flat.device
         segs = {name: (off, shape) for name, off, shape in model.param_segments()}
         g = geom
         shadow_shapes = [(32, g.K1, 1, g.K1), (64, g.K2, 32, 16), (64, g.K3, 64, 9), (g.HID, g.F, 64, g.P3)]
         total = sum(r * c for r, c, _, _ in shadow_shapes)
-        self.shadow = torch.zeros(total, dtype=BF16, device=dev)
+        self.shadow = torch.zeros(total * (2 if self.split else 1), dtype=BF16, device=dev)
+        self.shadow_plane = total if self.split else 0
         entries, self.w, self.b, self.off = [], [], [], {}
         soff = 0
         for li, layer in enumerate(self.ORDER):
@@ -156,7 +174,10 @@ class CnnWeights(object):
                 rows, cols, C, P = shadow_shapes[li]
                 assert rows == wshape[0] and cols == wn // wshape[0], (layer, wshape, rows, cols)
                 ent.update(C=C, P=P, shadow_off=soff, shadow_ld=cols, shadow=True)
-                self.w.append(self.shadow[soff:soff + rows * cols].view(rows, cols))
+                wv = self.shadow[soff:soff + rows * cols].view(rows, cols)
+                if self.split:      # hi-plane view + the offset of its lo plane, as the x3 kernels take operands
+                    wv = _PlaneView(wv, self.shadow[total + soff:total + soff + rows * cols].view(rows, cols))
+                self.w.append(wv)
                 soff += rows * cols
             else:
                 self.w.append(self.flat[woff:woff + wn].view(wshape))       # fc2 stays fp32
@@ -168,7 +189,7 @@ class CnnWeights(object):
 
     def refresh(self):
         """Rebuild the bf16 shadows from the fp32 master weights (after a load)."""
-        polyak_(self.flat, self.flat, 1.0, self.table, self.shadow)
+        polyak_(self.flat, self.flat, 1.0, self.table, self.shadow, self.shadow_plane)
 
     def _convert(self, vec, to_kernel):
         out = vec.clone()
@@ -200,9 +221,14 @@ class CnnWeights(object):
 
 
 class _Acts(object):
-    def __init__(self, geom, B, groups, device, backward):
+    def __init__(self, geom, B, groups, device, backward, split=False):
         g = geom
-        z = lambda *s, dtype=BF16: torch.zeros(*s, dtype=dtype, device=device)
+        self.split = bool(split)
+
+        def z(*s, dtype=BF16):
+            if self.split and dtype == BF16:        # hi + lo planes of a logical fp32 tensor
+                return nn.Planes(*s, device=device)
+            return torch.zeros(*s, dtype=dtype, device=device)
         self.a1 = [z(B * g.H1 * g.W1, 32) for _ in range(groups)]
         self.a2 = [z(B * g.H2 * g.W2, 64) for _ in range(groups)]
         self.a3 = [z(B * g.P3, 64) for _ in range(groups)]
@@ -215,13 +241,16 @@ class _Acts(object):
             self.da3 = z(B * g.P3, 64)
             self.da2 = z(B * g.H2 * g.W2, 64)
             self.da1 = z(B * g.H1 * g.W1, 32)
-            self.stack_dgrad = nn.cnn_dgrad_stack_supported(g.H, g.W, g.C)
+            self.stack_dgrad = nn.cnn_dgrad_stack_supported(g.H, g.W, g.C) and not self.split
             # gather-form data gradients need no dcol matrices; odd layer geometries fall back to
             # dcol GEMM + col2im
             # (measured on MI355X: the gather form is ~4 % slower end to end at batch 128 and 4096 --
             # 4-9 latency-bound k-tiles against one output-bound tile + a bandwidth pass -- so it is
             # opt-in; it saves the dcol buffers: 0.9 GB at batch 4096)
-            self.fused_dgrad = g.H1 % 2 == 0 and g.W1 % 2 == 0 and os.environ.get("PDA_FUSED_DGRAD", "0") == "1"
+            self.fused_dgrad = g.H1 % 2 == 0 and g.W1 % 2 == 0 and (os.environ.get("PDA_FUSED_DGRAD", "0") == "1"
+                                                                    or self.split)
+            if self.split and not self.fused_dgrad:
+                raise ValueError("the fp32-precision engine needs even conv1 output sides (gather-form dgrad)")
             if not self.fused_dgrad and not self.stack_dgrad:
                 self.dcol3 = z(B * g.P3, g.K3)
                 self.dcol2 = z(B * g.H2 * g.W2, g.K2)
@@ -239,6 +268,18 @@ def cnn_forward(geom, nets, frames, idxs, acts, B, norm_val, keep_first_only=Tru
     """Run len(nets) (<= 3) networks as problem groups of the same launches.
     Leaves fc1's pre-activation split-K sums in acts.h1pre[g] (which must be zero)."""
     g, n = geom, len(nets)
+    if getattr(acts, "split", False):
+        # fp32-precision learner: layer-wise implicit GEMMs on split-bf16 planes (csrc/gemm_x3.hip)
+        nn.x3_conv_fwd_u8(frames, idxs, [w.w[0] for w in nets], [w.b[0] for w in nets], acts.a1[:n], B,
+                          g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / float(norm_val))
+        nn.x3_conv_fwd(acts.a1[:n], [w.w[1] for w in nets], [w.b[1] for w in nets], acts.a2[:n], B, g.H1, g.W1, 32,
+                       4, 4, 2, 64)
+        nn.x3_conv_fwd(acts.a2[:n], [w.w[2] for w in nets], [w.b[2] for w in nets], acts.a3[:n], B, g.H2, g.W2, 64,
+                       3, 3, 1, 64)
+        tiles = ((B + 63) // 64) * (g.HID // 64) * n
+        nn.x3_linear_fwd(acts.a3[:n], [w.w[3] for w in nets], acts.h1pre[:n], B, g.HID, g.F, g.F, g.F, g.HID,
+                         ksplit=_ksplit(3 * g.F, tiles, _FC1_BLOCKS, 128))
+        return
     if nn.cnn_fwd_stack_supported(g.H, g.W, g.C):
         # one launch, one workgroup per image; only group 0 (the trained network on s0) keeps a1 / a2
         keep = [True] + [False] * (n - 1) if keep_first_only else [True] * n
@@ -261,31 +302,37 @@ class DqnCnnEngine(object):
     """One learner's device state and step program."""
 
     def __init__(self, model, target_model, batch_size, lr=1e-4, weight_decay=0.0, clip=np.inf,
-                 double=False, target_update=250, per=None, seed=0, tail_offsets=(0, 1, 2, 3)):
+                 double=False, target_update=250, per=None, seed=0, tail_offsets=(0, 1, 2, 3), precision="bf16"):
+        """precision: "bf16" = bf16 MFMA operands (per-image fused conv kernels); "fp32" = every product a
+        split-bf16 x3 product with fp32 accumulation (csrc/gemm_x3.hip), the reference learner's precision."""
         self.geom = g = CnnGeometry(model.input_dims, model.output_dims, model.critic[1][0].out_features)
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32', not %r" % (precision,))
+        self.precision = precision
+        self.x3 = x3 = precision == "fp32"
         self.B = int(batch_size)
         self.norm_val = float(model.norm_val)
         self.double = bool(double)
         self.target_update = target_update
         self.per = per                      # None or dict(eps, alpha, beta)
-        self.online = CnnWeights(model, g, with_grad=True)
-        self.target = CnnWeights(target_model, g, with_grad=False)
+        self.online = CnnWeights(model, g, with_grad=True, split=x3)
+        self.target = CnnWeights(target_model, g, with_grad=False, split=x3)
         self.device = dev = self.online.flat.device
         self.grads = model.flat_grads
         self.grads.zero_()
         self.gw, self.gb = self.online.grad_views(self.grads)
         self.adam = FlatAdam(self.online.flat, self.grads, self.online.table, lr=lr, weight_decay=weight_decay,
-                             clip=clip, shadow=self.online.shadow)
+                             clip=clip, shadow=self.online.shadow, shadow_plane=self.online.shadow_plane)
         self.groups = 3 if self.double else 2
-        self.acts = _Acts(g, self.B, self.groups, dev, backward=True)
-        self.pair_wgrad = bool(self.acts.stack_dgrad) and os.environ.get("PDA_PAIR_WGRAD", "1") != "0"
+        self.acts = _Acts(g, self.B, self.groups, dev, backward=True, split=x3)
+        self.pair_wgrad = (bool(self.acts.stack_dgrad) or x3) and os.environ.get("PDA_PAIR_WGRAD", "1") != "0"
         # large batches: conv2 + conv3 weight gradients per image with register accumulation (csrc/conv1_kernels.hip)
-        self.stack_wgrad = bool(self.acts.stack_dgrad) and self.B >= _WGRAD_STACK_MIN
+        self.stack_wgrad = bool(self.acts.stack_dgrad) and self.B >= _WGRAD_STACK_MIN and not x3
         # fc1's data gradient in the launch of the two fc weight gradients (small batches: all three under-fill the GPU)
         self.fc_duo = self.B <= 512 and not self.overlap_wgrad_env() and os.environ.get("PDA_FC_DUO", "1") != "0"
         # conv1's weight gradient as a tail of the dgrad stack launch (da1 still in LDS)
         self.fuse_w1 = (bool(self.acts.stack_dgrad) and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32)
-                        and os.environ.get("PDA_FUSE_W1", "1") != "0")
+                        and os.environ.get("PDA_FUSE_W1", "1") != "0" and not x3)
         self._plan_wgrads()
         self._fc_pair = None
         self.idx = torch.zeros(self.B, dtype=torch.int32, device=dev)
@@ -310,14 +357,20 @@ class DqnCnnEngine(object):
         # (measured: 4828 vs 5240 updates/s -- cross-stream edges inside a hipGraph cost more than the
         # overlap returns on this runtime, so the branch is off unless asked for)
         self.overlap_wgrad = os.environ.get("PDA_OVERLAP_WGRAD", "0") == "1"
-        polyak_(self.target.flat, self.online.flat, 1.0, self.target.table, self.target.shadow)   # hard copy to start
+        self._target_copy(1.0)      # hard copy to start
+
+    def _target_copy(self, tau):
+        t = self.target
+        polyak_(t.flat, self.online.flat, float(tau), t.table, t.shadow, t.shadow_plane)
 
     def _plan_wgrads(self):
         """Split-K plan of the three conv weight gradients: slab sizes + the one reduce launch."""
         g, B, dev = self.geom, self.B, self.device
         plans = []      # (layer, O, K, red)
-        for li, (O, K, red) in enumerate([(32, g.K1, B * g.H1 * g.W1), (64, g.K2, B * g.H2 * g.W2),
-                                          (64, g.K3, B * g.P3)]):
+        # fp32 precision: the reduction carries the operand copies (gemm.h SrcSplit): x2 against uint8 frames, else x3
+        mult = (2, 3, 3) if self.x3 else (1, 1, 1)
+        for li, (O, K, red) in enumerate([(32, g.K1, mult[0] * B * g.H1 * g.W1), (64, g.K2, mult[1] * B * g.H2 * g.W2),
+                                          (64, g.K3, mult[2] * B * g.P3)]):
             tiles = ((O + 63) // 64 if O > 32 else 1) * ((K + 63) // 64)
             ks = _ksplit(red, tiles, _WGRAD_BLOCKS, 128)
             if li > 0 and self.stack_wgrad:
@@ -325,10 +378,10 @@ class DqnCnnEngine(object):
             elif li > 0 and self.pair_wgrad:
                 # conv2 + conv3 go out as two problem groups of one launch with a common slice length, sized so
                 # that the launch as a whole is ~_PAIR_BLOCKS workgroups
-                work = 8 * (B * g.H2 * g.W2) + 9 * (B * g.P3)
+                work = mult[1] * (8 * (B * g.H2 * g.W2) + 9 * (B * g.P3))
                 ks = nn.round_ksplit(max(128, (work + _PAIR_BLOCKS - 1) // _PAIR_BLOCKS))
             ns = nn.num_slices(red, ks) if ks > 0 else ns_override
-            if li == 0 and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32):
+            if li == 0 and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32) and not self.x3:
                 ns = nn.conv1_wgrad_slices(B)       # whole-image kernel: one slice per workgroup
                 if self.fuse_w1:
                     ns = nn.cnn_dgrad_stack_slices(B)   # computed by the dgrad stack launch itself
@@ -408,7 +461,9 @@ class DqnCnnEngine(object):
             leaf_sum=_p(tree.sum) if tree is not None else 0, leaf_min=_p(tree.min) if tree is not None else 0,
             prio_eps=float(self.per["eps"]) if self.per else 0.0,
             prio_alpha=float(self.per["alpha"]) if self.per else 1.0,
-            B=B, HID=g.HID, A=g.A, rng_counter=_p(self.counter), opt_step=_p(self.adam.step_dev))
+            B=B, HID=g.HID, A=g.A, rng_counter=_p(self.counter), opt_step=_p(self.adam.step_dev),
+            h1_plane=getattr(a.h1, "plane", 0), dh1_plane=getattr(a.dh1, "plane", 0),
+            dq_plane=getattr(a.dq, "plane", 0))
         _L().pda_dqn_head(ctypes.byref(args), _stream())
 
     @staticmethod
@@ -419,14 +474,14 @@ class DqnCnnEngine(object):
         g, B, a = self.geom, self.B, self.acts
         # one slice each, written straight into the gradient buffer (kernel layout); both in one launch
         if self._fc_pair is None:
-            self._fc_pair = nn.LinearWgradPair(
+            self._fc_pair = (nn.X3LinearWgradPair if self.x3 else nn.LinearWgradPair)(
                 [(a.dh1, a.a3[0], self.gw[3], self.gb[3], g.HID, g.F, g.HID, g.F, g.F),
                  (a.dq, a.h1, self.gw[4], self.gb[4], g.A, g.HID, a.dq_ld, g.HID, g.HID)], B)
         if self.fc_duo:
             # ... and fc1's data gradient rides in the same launch (backward_conv then starts at the conv stack)
             on = self.online
-            self._fc_pair.run_with_dgrad(a.dh1, on.w[3], a.a3[0], a.da3, B, g.HID, g.F, g.HID, g.F, g.F, g.F,
-                                         act=nn.ACT_RELU)
+            self._fc_pair.run_with_dgrad(a.dh1, on.w[3], a.a3[0].hi if self.x3 else a.a3[0], a.da3, B, g.HID, g.F,
+                                         g.HID, g.F, g.F, g.F, act=nn.ACT_RELU)
         else:
             self._fc_pair.run()
 
@@ -464,6 +519,26 @@ class DqnCnnEngine(object):
                 side.wait_event(ready)
                 fn()
 
+        if self.x3:
+            # fp32 precision: gather-form data gradients and split-K weight gradients on split-bf16 planes
+            if not self.fc_duo:
+                nn.x3_linear_dgrad(a.dh1, on.w[3], a.a3[0].hi, a.da3, B, g.HID, g.F, g.HID, g.F, g.F, g.F,
+                                   act=nn.ACT_RELU)
+            nn.x3_conv_dgrad(a.da3, on.w[2], a.a2[0].hi, a.da2, B, g.H2, g.W2, 64, 3, 3, 1, 64, act=nn.ACT_RELU)
+            nn.x3_conv_dgrad(a.da2, on.w[1], a.a1[0].hi, a.da1, B, g.H1, g.W1, 32, 4, 4, 2, 64, act=nn.ACT_RELU)
+            geoms = [(g.H1, g.W1, 32, 4, 4, 2), (g.H2, g.W2, 64, 3, 3, 1)]
+            if self.pair_wgrad:
+                assert ks2 == ks3
+                nn.x3_conv_wgrad([a.da2, a.da3], [a.a1[0], a.a2[0]], [w2s, w3s], [b2s, b3s], B, geoms, 64, ks2,
+                                 [st2, st3], [bst2, bst3])
+            else:
+                nn.x3_conv_wgrad([a.da3], [a.a2[0]], [w3s], [b3s], B, geoms[1:], 64, ks3, [st3], [bst3])
+                nn.x3_conv_wgrad([a.da2], [a.a1[0]], [w2s], [b2s], B, geoms[:1], 64, ks2, [st2], [bst2])
+            nn.x3_conv_wgrad_u8(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / self.norm_val,
+                                ksplit=ks1, slice_stride=st1, bslice_stride=bst1)
+            if reduce:
+                self.reduce.run()
+            return False
         if not self.fc_duo:
             nn.linear_dgrad(a.dh1, on.w[3], a.a3[0], a.da3, B, g.HID, g.F, g.HID, g.F, g.F, g.F, act=nn.ACT_RELU)
         if a.stack_dgrad:
@@ -530,13 +605,12 @@ class DqnCnnEngine(object):
     def post_update(self, staged=False):
         """What follows the optimizer: soft target update, sum/min-tree repair of the sampled leaves."""
         if self.target_update < 1.0:
-            polyak_(self.target.flat, self.online.flat, float(self.target_update), self.target.table,
-                    self.target.shadow)
+            self._target_copy(self.target_update)
         if not staged and self.per is not None and self.replay[3] is not None:
             self.replay[3].repair(self.idx, self.B)
 
     def hard_target_update(self):
-        polyak_(self.target.flat, self.online.flat, 1.0, self.target.table, self.target.shadow)
+        self._target_copy(1.0)
 
     def set_size(self, n):
         self.size_dev.fill_(int(n))
@@ -797,7 +871,8 @@ class DqnNativeCore(object):
         self.engine = DqnCnnEngine(model, target_model, ap.batch_size, lr=ap.lr, weight_decay=ap.weight_decay,
                                    clip=ap.clip_grad, double=ap.enable_double,
                                    target_update=ap.target_model_update, per=per,
-                                   seed=args.seed * 7919 + 104729 * rank + 13, tail_offsets=(0, a, a + k, a + 2 * k))
+                                   seed=args.seed * 7919 + 104729 * rank + 13, tail_offsets=(0, a, a + k, a + 2 * k),
+                                   precision=getattr(args, "precision", "bf16"))
         self.on_device = hasattr(memory, "tails") and getattr(memory, "attached", False) and memory.tails.is_cuda
         if self.on_device:
             self.engine.bind_replay(memory.state0s, memory.state1s, memory.tails, memory.tree)

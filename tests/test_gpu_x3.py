@@ -178,3 +178,182 @@ def test_x3_linear_family(nn):
         assert rel(gb, dy.double().sum(0)) < TOL
         assert rel(gw2, dq[:, :6].double().t() @ h.double()) < TOL
         assert rel(gb2, dq[:, :6].double().sum(0)) < TOL
+
+
+# ---- the engine at fp32 precision ------------------------------------------------------------------------------
+def _models(A=6, seed=0):
+    from pytorch_distributed_amd.models.dqn_cnn_model import DqnCnnModel
+    from pytorch_distributed_amd.utils.options import Options
+    torch.manual_seed(seed)
+    opt = Options(config=2)
+    m = DqnCnnModel(opt.model_params, 255.0, (4, 84, 84), A, 1).cuda()
+    t = DqnCnnModel(opt.model_params, 255.0, (4, 84, 84), A, 1).cuda()
+    return m, t
+
+
+def _batch(B, A, seed=1):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    s0 = torch.randint(0, 256, (B, 4, 84, 84), dtype=torch.uint8, device="cuda", generator=g)
+    s1 = torch.randint(0, 256, (B, 4, 84, 84), dtype=torch.uint8, device="cuda", generator=g)
+    tails = torch.zeros(B, 5, device="cuda")
+    tails[:, 0] = torch.randint(0, A, (B,), device="cuda", generator=g).float()
+    tails[:, 1] = torch.randn(B, device="cuda", generator=g)
+    tails[:, 2] = 0.99 ** 5
+    tails[:, 3] = (torch.rand(B, device="cuda", generator=g) < 0.1).float()
+    return s0, s1, tails
+
+
+def _torch_step(model, target, s0, s1, tails, double):
+    """The reference learner's arithmetic (core/single_processes/dqn_learner.py:67-80), in fp64."""
+    import copy
+    model, target = copy.deepcopy(model).double(), copy.deepcopy(target).double()
+
+    def fwd(net, s):        # DqnCnnModel.forward in fp64 (the module's own forward casts its input to fp32)
+        x = net.critic[0](s.double() / 255.0)
+        return net.critic[1](x.flatten(1))
+    a, r, g, t = (tails[:, i:i + 1].double() for i in range(4))
+    with torch.no_grad():
+        if double:
+            nq = fwd(target, s1).gather(1, fwd(model, s1).argmax(1, keepdim=True))
+        else:
+            nq = fwd(target, s1).max(1, keepdim=True)[0]
+        y = r + g * nq * (1 - t)
+    q = fwd(model, s0)
+    pred = q.gather(1, a.long())
+    loss = ((pred - y) ** 2).mean()
+    loss.backward()
+    return model, q.detach(), (pred - y).detach().reshape(-1), loss.item()
+
+
+@pytest.mark.parametrize("B,double,A", [(128, False, 6), (32, True, 18)])
+def test_engine_fp32_precision_gradients_match_fp64_torch(nn, B, double, A):
+    """Per-layer gradients of the fp32-precision engine within 1e-3 (relative L2) of the reference learner's
+    step -- the bf16 engine is allowed 6-12 % here (tests/test_gpu_dqn_engine.py)."""
+    from pytorch_distributed_amd.ops import dqn_engine as eng
+    model, target = _models(A)
+    e = eng.DqnCnnEngine(model, target, B, double=double, target_update=10 ** 9, precision="fp32")
+    assert e.x3 and e.online.shadow_plane > 0
+    with torch.no_grad():
+        for p in target.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    e.target.refresh()
+    # split shadows carry 16 significand bits of the masters
+    w4 = model.critic[1][0].weight.detach()
+    got = e.online.w[3].value()
+    want = w4.reshape(512, 64, 49).permute(0, 2, 1).reshape(512, -1)
+    assert rel(got, want) < 2 ** -16
+    s0, s1, tails = _batch(B, A)
+    e.make_staging(5)
+    e.stage_s0.copy_(s0); e.stage_s1.copy_(s1); e.stage_tails.copy_(tails)
+    e.forward_head(staged=True)
+    e.backward_fc()
+    e.backward_conv(staged=True)
+    torch.cuda.synchronize()
+    ref, q_ref, td_ref, loss_ref = _torch_step(model, target, s0, s1, tails, double)
+    assert rel(e.q, q_ref) < 1e-4
+    assert rel(e.td, td_ref) < 1e-4
+    assert abs(e.loss_acc.sum().item() - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    grads = e.grads_torch_layout()
+    off, errs = 0, {}
+    for name, p in ref.named_parameters():
+        got = grads[off:off + p.numel()].view_as(p)
+        off += p.numel()
+        errs[name] = ((got.double() - p.grad).norm() / p.grad.norm().clamp_min(1e-30)).item()
+    print("fp32-precision grad rel errs vs fp64:", {k: float("%.2g" % v) for k, v in errs.items()})
+    # What an fp32 PyTorch step (the reference learner's own arithmetic) deviates from the same fp64 step by.  ReLU's
+    # derivative is discontinuous: a unit whose pre-activation lies within an implementation's rounding error of zero
+    # passes its whole gradient in one implementation and nothing in the other, so ANY two finite-precision steps
+    # disagree by ~sqrt(fraction of such units) on the conv gradients.
+    import copy
+    m32 = copy.deepcopy(model)
+    m32.zero_grad(set_to_none=True)
+    a_, r_, g_, t_ = (tails[:, i:i + 1] for i in range(4))
+    with torch.no_grad():
+        nq = (target(s1).gather(1, m32(s1).argmax(1, keepdim=True)) if double else target(s1).max(1, keepdim=True)[0])
+        y32 = r_ + g_ * nq * (1 - t_)
+    ((m32(s0).gather(1, a_.long()) - y32) ** 2).mean().backward()
+    errs32 = {n: ((p32.grad.double() - p.grad).norm() / p.grad.norm()).item()
+              for (n, p32), (_, p) in zip(m32.named_parameters(), ref.named_parameters())}
+    print("fp32 torch grad rel errs vs fp64:    ", {k: float("%.2g" % v) for k, v in errs32.items()})
+    for name, err in errs.items():
+        limit = 5e-3 if name.startswith("critic.0") else 1e-4      # conv layers: mask flips; fc layers: arithmetic
+        assert err < limit, "%s: rel err %g (all: %s)" % (name, err, errs)
+
+    # The arithmetic alone, with the discontinuity taken out: the same fp64 step run with the ENGINE's ReLU masks
+    # (units the two implementations disagree on are counted, and must be a handful per million).
+    masks = {"a1": e.acts.a1[0].hi.view(B, 20, 20, 32).permute(0, 3, 1, 2) > 0,
+             "a2": e.acts.a2[0].hi.view(B, 9, 9, 64).permute(0, 3, 1, 2) > 0,
+             "a3": e.acts.a3[0].hi.view(B, 7, 7, 64).permute(0, 3, 1, 2) > 0,
+             "h1": e.acts.h1.hi > 0}
+    m64 = copy.deepcopy(model).double()
+    c, f = m64.critic[0], m64.critic[1]
+    flips, total = 0, 0
+
+    def masked(pre, mask):
+        nonlocal flips, total
+        flips += int(((pre > 0) != mask).sum().item())
+        total += mask.numel()
+        return pre * mask.double()
+    x = masked(c[0](s0.double() / 255.0), masks["a1"])
+    x = masked(c[2](x), masks["a2"])
+    x = masked(c[4](x), masks["a3"])
+    h = masked(f[0](x.flatten(1)), masks["h1"])
+    q = f[2](h)
+    y = (q_ref.gather(1, a_.long()) - td_ref[:, None]).detach()        # the fp64 step's own TD target
+    ((q.gather(1, a_.long()) - y) ** 2).mean().backward()
+    errs_m = {}
+    off = 0
+    for name, p in m64.named_parameters():
+        got = grads[off:off + p.numel()].view_as(p)
+        off += p.numel()
+        errs_m[name] = ((got.double() - p.grad).norm() / p.grad.norm().clamp_min(1e-30)).item()
+    print("fp32-precision grad rel errs vs fp64 with the engine's ReLU masks:",
+          {k: float("%.2g" % v) for k, v in errs_m.items()}, "| mask disagreements: %d of %d units" % (flips, total))
+    assert flips <= 1e-4 * total
+    for name, err in errs_m.items():
+        assert err < 1e-4, "%s: rel err %g with identical masks (all: %s)" % (name, err, errs_m)
+
+
+def test_engine_fp32_precision_adam_keeps_split_shadows(nn):
+    from pytorch_distributed_amd.ops import dqn_engine as eng
+    model, target = _models()
+    e = eng.DqnCnnEngine(model, target, 32, lr=1e-3, target_update=2, precision="fp32")
+    torch.manual_seed(3)
+    for _ in range(3):
+        e.grads.copy_(e.online.to_kernel_layout(torch.randn_like(e.grads) * 0.1))
+        e.update(staged=True, tick=True)
+    torch.cuda.synchronize()
+    from pytorch_distributed_amd.ops import nn as pnn
+    w2 = model.critic[0][2].weight.detach()
+    want = w2.permute(0, 2, 3, 1).reshape(64, -1)
+    assert torch.equal(e.online.w[1].hi, pnn.pack_conv_weight(w2))
+    assert rel(e.online.w[1].value(), want) < 2 ** -16
+    e.hard_target_update()
+    assert torch.equal(e.target.flat, e.online.flat)
+    assert torch.equal(e.target.shadow, e.online.shadow)
+
+
+def test_engine_fp32_precision_steps_from_hbm_replay_in_a_graph(nn):
+    from pytorch_distributed_amd.ops import dqn_engine as eng
+    B, mem_n = 64, 512
+    s0, s1, tails = _batch(B, 6)
+    tails[:, 3] = 1.0           # terminal: pure regression onto the rewards
+    g = torch.Generator(device="cuda").manual_seed(2)
+    frames = torch.randint(0, 256, (mem_n, 4, 84, 84), dtype=torch.uint8, device="cuda", generator=g)
+    rt = tails[torch.arange(mem_n, device="cuda") % B].contiguous()
+    model, target = _models(seed=7)
+    e = eng.DqnCnnEngine(model, target, B, lr=3e-4, target_update=1000, seed=11, precision="fp32")
+    e.bind_replay(frames, frames.flip(0).contiguous(), rt, None)
+    e.set_size(mem_n)
+    prog = eng.DqnStepProgram(e, None, use_graph=True, staged=False, graph_steps=5)
+    prog.step()
+    first = e.mean_loss()
+    for _ in range(200):
+        prog.step()
+    e.mean_loss()
+    for _ in range(10):
+        prog.step()
+    last = e.mean_loss()
+    torch.cuda.synchronize()
+    assert prog.graphs is not None and prog.graph_steps == 5
+    assert last == last and last < 0.5 * first, (first, last)
