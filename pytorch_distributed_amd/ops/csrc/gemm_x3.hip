@@ -118,6 +118,7 @@ PDA_EXPORT void pda_x3_conv_dgrad(const void* dy, long dy_plane, const void* w, 
             ++ng;
         }
     if (C <= 32) launch_gemm<64, 32, 4, 1>(a, ng, maxM, C, 3 * K, 0, stream);
+    else if (small_grid(maxM, C, ng)) launch_gemm<32, 64, 1, 4>(a, ng, maxM, C, 3 * K, 0, stream);
     else launch_gemm<64, 64, 2, 2>(a, ng, maxM, C, 3 * K, 0, stream);
 }
 

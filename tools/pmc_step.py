@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--replay", type=int, default=8192)
     ap.add_argument("--per", action="store_true")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     a = ap.parse_args()
     import torch
     from pytorch_distributed_amd import ops
@@ -49,7 +50,7 @@ def main():
         tree = DeviceSumMinTree(m, dev)
         tree.update(torch.arange(m, device=dev, dtype=torch.int32), torch.rand(m, device=dev) + 0.05)
         per = {"eps": 1e-6, "alpha": 0.5, "beta": 0.4}
-    eng = DqnCnnEngine(model, target, a.batch, per=per).bind_replay(s0, s1, tails, tree)
+    eng = DqnCnnEngine(model, target, a.batch, per=per, precision=a.precision).bind_replay(s0, s1, tails, tree)
     eng.set_size(m)
     prog = DqnStepProgram(eng, None, use_graph=False)
     for _ in range(a.steps):

@@ -19,6 +19,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# SQ_VALU_MFMA_BUSY_CYCLES per matrix-pipe busy cycle (summed over the chip's SIMDs).  Calibrated on a launch whose
+# MFMA count is known exactly (the fc1 forward GEMM, cross-check line at the end of every counter file): the counter
+# reads 16.00 per v_mfma_f32_16x16x32_bf16, which holds its SIMD's matrix pipe for 16 cycles => 1 tick per busy cycle.
+MFMA_COUNTER_PER_CYCLE = 1.0
+MFMA_CYCLES_16x16x32 = 16.0
+
 GROUPS = {
     "sq": ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU",
            "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_ANY"],
@@ -51,6 +57,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--tag", default="step")
     ap.add_argument("--per", action="store_true")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     a = ap.parse_args()
     out = os.path.join(ROOT, "gpurun_out", a.tag)      # text summaries and pass logs (merged back by gpurun)
     raw = os.path.join("/tmp", "pda_prof", a.tag)       # rocprofv3 databases: large, stay on the GPU box
@@ -60,7 +67,7 @@ def main():
     env_tmp = "/tmp"
     os.environ["TMPDIR"] = env_tmp
     target = [sys.executable, os.path.join(ROOT, "tools", "pmc_step.py"), "--batch", str(a.batch),
-              "--steps", str(a.steps)] + (["--per"] if a.per else [])
+              "--steps", str(a.steps), "--precision", a.precision] + (["--per"] if a.per else [])
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from rocpd_summary import short
 
@@ -98,26 +105,52 @@ def main():
     with open(path, "w") as fh:
         fh.write("# hardware counters of the native DQN learner step, batch %d, %d eager steps (tools/profile_step.py)\n"
                  % (a.batch, a.steps))
-        fh.write("# mfma_busy%% = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CYCLES)   [4 SIMDs per CU report into one SQ]\n")
+        fh.write("# mfma_busy%% = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * kernel time * 2.4 GHz): the counter adds, over every\n"
+                 "#   SIMD of the chip, the cycles its matrix pipe is busy (cross-check at the end: it reads 16.00 per\n"
+                 "#   v_mfma_f32_16x16x32_bf16, which holds its pipe for 16 cycles); at the 2.4 GHz ceiling clock this is a LOWER\n"
+                 "#   bound of the pipe's duty cycle (the chip clocks lower under load) and cannot exceed 100 %%.\n"
+                 "#   mfma_cnt = SQ_VALU_MFMA_BUSY_CYCLES / 16 = 16x16x32 MFMA wave-instructions per launch.\n")
         fh.write("# lds_conflict%% = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE;  wait%% = SQ_WAIT_ANY / SQ_WAVE_CYCLES\n")
         fh.write("# hbm MB/launch = (2*FETCH_SIZE + WRITE_SIZE) KB / 1024 per dispatch (gfx950 FETCH_SIZE counts half of a wide read)\n")
-        fh.write("%-72s %6s %9s %8s %10s %8s %8s %9s %9s %8s\n" % (
-            "kernel", "calls", "us/call", "waves", "mfma_busy%", "lds_cf%", "wait%", "rd_MB", "wr_MB", "L2hit%"))
+        fh.write("%-72s %6s %9s %8s %10s %10s %8s %8s %9s %9s %8s\n" % (
+            "kernel", "calls", "us/call", "waves", "mfma_busy%", "mfma_cnt", "lds_cf%", "wait%", "rd_MB", "wr_MB",
+            "L2hit%"))
         for k in sorted(merged, key=lambda n: -durs.get(n, 0)):
             c = merged[k]
             g = lambda name: (c.get(name, (0, 0.0))[1])
             n = max(c.get("SQ_WAVES", (1, 0))[0], 1)
-            busy = g("SQ_BUSY_CYCLES")
-            mf = 100.0 * g("SQ_VALU_MFMA_BUSY_CYCLES") / (4.0 * busy) if busy else 0.0
+            ncalls = max(calls.get(k, n), 1)
+            us_call = durs.get(k, 0) / 1e3 / ncalls
+            mfma_raw = g("SQ_VALU_MFMA_BUSY_CYCLES") / n          # per launch, summed over the chip
+            mf = 100.0 * mfma_raw / MFMA_COUNTER_PER_CYCLE / (1024.0 * us_call * 2400.0) if us_call else 0.0
             ldsa = g("SQ_LDS_IDX_ACTIVE")
             cf = 100.0 * g("SQ_LDS_BANK_CONFLICT") / ldsa if ldsa else 0.0
             wc = g("SQ_WAVE_CYCLES")
             wt = 100.0 * g("SQ_WAIT_ANY") / wc if wc else 0.0
             hit, miss = g("TCC_HIT_sum"), g("TCC_MISS_sum")
             l2 = 100.0 * hit / (hit + miss) if hit + miss else 0.0
-            fh.write("%-72s %6d %9.2f %8.0f %10.1f %8.1f %8.1f %9.2f %9.2f %8.1f\n" % (
-                short(k, 72), calls.get(k, n), durs.get(k, 0) / 1e3 / max(calls.get(k, n), 1), g("SQ_WAVES") / n,
-                mf, cf, wt, 2.0 * g("FETCH_SIZE") / n / 1024.0, g("WRITE_SIZE") / n / 1024.0, l2))
+            fh.write("%-72s %6d %9.2f %8.0f %10.1f %10.0f %8.1f %8.1f %9.2f %9.2f %8.1f\n" % (
+                short(k, 72), calls.get(k, n), us_call, g("SQ_WAVES") / n,
+                mf, mfma_raw / MFMA_CYCLES_16x16x32, cf, wt, 2.0 * g("FETCH_SIZE") / n / 1024.0, g("WRITE_SIZE") / n / 1024.0, l2))
+        # hand cross-check of the MFMA counter on a launch whose instruction count is known exactly: the fc1 forward
+        # GEMM (64x64 tiles, 4 waves x 2x2 fragments of 16x16x32): per launch
+        #   groups * ceil(B/64) * (512/64) tiles * sum over k-slices of ceil(len/64) k-tiles * 2 k-steps * 16 MFMA per tile
+        for k, c in merged.items():
+            if "EpiAtomicF32" in k and "SrcDenseK" in k and "SrcSplit" not in k and a.precision == "bf16":
+                import math
+                B, F, HID, groups = a.batch, 3136, 512, 2
+                tiles = groups * math.ceil(B / 64) * (HID // 64)
+                target_blocks = int(os.environ.get("PDA_FC1_BLOCKS", "256"))
+                slices = max(1, target_blocks // max(tiles, 1))
+                ks = max(128, math.ceil(F / slices))
+                ks = (ks + 63) // 64 * 64
+                ktiles = sum(math.ceil((min(F, s0 + ks) - s0) / 64) for s0 in range(0, F, ks))
+                expect = tiles * ktiles * 2 * 16
+                nn_ = max(c.get("SQ_WAVES", (1, 0))[0], 1)
+                got = c.get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0.0))[1] / nn_
+                fh.write("# cross-check (%s): %d MFMA wave-instructions per launch by hand; counter %.0f = %.2f per "
+                         "instruction (16 pipe cycles each => the counter ticks %.2f x per busy cycle)\n"
+                         % (short(k, 60), expect, got, got / expect, got / expect / 16.0))
     shutil.copy(path, os.path.join(out, os.path.basename(path)))
     print(open(path).read())
     return 0
