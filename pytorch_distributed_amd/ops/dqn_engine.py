@@ -687,9 +687,22 @@ class DqnStepProgram(object):
             # (PDA_DP_GRAD_DTYPE=bf16 | fp32, default fp32: the two conversion launches cost ~20 us per step in the
             # 1-rank rehearsal -- 9.2k vs 7.8k updates/s -- so it only pays where the all-reduce saves more than that.)
             self.grad_dtype = os.environ.get("PDA_DP_GRAD_DTYPE", "fp32").lower()
-            if getattr(comm, "backend", None) != "nccl":
+            # The all-reduce itself: the one-kernel xGMI peer all-reduce (parallel/peer_allreduce.py: every rank maps
+            # every peer's hand-off region through hipIpc; two hops over all links, replayable inside the step graph)
+            # when it passes its self-test on every rank, else the process group's (RCCL ring / gloo).
+            # PDA_DP_ALLREDUCE=auto|peer|rccl.
+            from ..parallel.peer_allreduce import make_grad_allreduce
+            kind = os.environ.get("PDA_DP_ALLREDUCE", "auto")
+            if not hasattr(comm, "backend") or not self.tail.is_cuda:
+                kind = "rccl"           # FakeComm / CPU tensors: the communicator's own reduce
+            self.ar_tail = make_grad_allreduce(comm, self.tail, kind, wire=self.grad_dtype)
+            self.ar_head = make_grad_allreduce(comm, self.head, kind)
+            self.allreduce_kind = self.ar_tail.kind
+            self.peer = self.allreduce_kind.startswith("peer")
+            if getattr(comm, "backend", None) != "nccl" and not self.peer:
                 self.grad_dtype = "fp32"        # host back-ends (gloo rehearsals, tests) reduce the fp32 buffer
-            self.tail16 = torch.empty_like(self.tail, dtype=BF16) if self.grad_dtype == "bf16" else None
+            self.tail16 = (torch.empty_like(self.tail, dtype=BF16)
+                           if self.grad_dtype == "bf16" and not self.peer else None)
 
     def _part_a(self):
         if not self.staged and not (self.presampled and self.e.presamples(self.staged)):
@@ -774,13 +787,13 @@ class DqnStepProgram(object):
                 self.comm.all_reduce_sum_(self.tail16)
                 self.tail.copy_(self.tail16)
             else:
-                self.comm.all_reduce_sum_(self.tail)
+                self.ar_tail.all_reduce_sum_(self.tail)     # (peer kernel: bf16 wire conversion happens in it)
             self.tail_done.record(self.comm_stream)
         b()
         self.conv_done.record(cur)
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(self.conv_done)
-            self.comm.all_reduce_sum_(self.head)
+            self.ar_head.all_reduce_sum_(self.head)
             self.head_done.record(self.comm_stream)
         cur.wait_event(self.tail_done)
         e.adam.step(table=self.tail_table)          # fc tail update runs under the conv all-reduce
@@ -801,6 +814,8 @@ class DqnStepProgram(object):
         a pre-flight child process (parallel/preflight.py) that tries the capture first.
         Every rank takes the same decision (MIN over ranks)."""
         mode = os.environ.get("PDA_DP_GRAPH", "auto")
+        if self.peer and mode != "split":
+            mode = "whole"      # the peer all-reduce is a plain kernel launch: nothing host-driven is left in the step
         if mode == "auto":
             mode = "whole" if getattr(self.comm, "backend", None) == "nccl" else "split"
         whole = self.comm.all_agree(mode == "whole")

@@ -1,0 +1,282 @@
+"""Gradient all-reduce over direct peer stores (xGMI): python side of ops/csrc/peer_allreduce.hip.
+
+SURVEY.md 5.8: the learner's collective is ONE small message (6.75 MB fp32 for the Nature CNN) every
+~80 us of compute, so it is latency-bound; a ring pushes it over one link per GPU in 2(N-1) hops, while
+an MI355X node is fully connected.  `PeerAllReduce` maps one uncached hand-off region per rank into
+every peer (hipIpcGetMemHandle / hipIpcOpenMemHandle, handles exchanged over the existing process group)
+and reduces with a single two-hop kernel that drives all links at once, takes no per-call argument (its
+epoch lives in device memory) and therefore replays inside the learner step's hipGraph.
+
+The reference has no counterpart: its extra learners write one shared CUDA model without any exchange
+(Hogwild), and the A3C-style `ensure_global_grads` hand-off is dead code
+(utils/helpers.py:28-34, core/single_processes/dqn_learner.py:85-86).
+
+`make_grad_allreduce(comm, flat, kind)` picks the implementation for a bucket:
+  "rccl"  torch.distributed all_reduce (RCCL on GPU, gloo on CPU)
+  "peer"  the kernel here (raises if the regions cannot be mapped)
+  "auto"  peer when every rank maps every peer AND a self-test all-reduce returns the right sums on all
+          ranks, otherwise RCCL -- decided collectively, so all ranks run the same algorithm
+"""
+import ctypes
+import os
+
+import torch
+
+try:
+    import torch.distributed as dist
+except Exception:   # pragma: no cover
+    dist = None
+
+_vp = ctypes.c_void_p
+MAX_RANKS = 8
+
+
+def _lib():
+    from ..ops import lib
+    L = lib()
+    if not getattr(L, "_peer_ready", False):
+        L.pda_peer_plan.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.POINTER(ctypes.c_long),
+                                    ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_int)]
+        L.pda_peer_plan.restype = None
+        L.pda_peer_region_bytes.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int]
+        L.pda_peer_region_bytes.restype = ctypes.c_long
+        L.pda_peer_alloc.argtypes = [ctypes.c_long, ctypes.POINTER(_vp), ctypes.c_char_p]
+        L.pda_peer_alloc.restype = ctypes.c_int
+        L.pda_peer_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(_vp)]
+        L.pda_peer_open.restype = ctypes.c_int
+        L.pda_peer_close.argtypes = [_vp]
+        L.pda_peer_close.restype = ctypes.c_int
+        L.pda_peer_free.argtypes = [_vp]
+        L.pda_peer_free.restype = ctypes.c_int
+        L.pda_peer_error.argtypes = [_vp]
+        L.pda_peer_error.restype = ctypes.c_int
+        L.pda_peer_allreduce.argtypes = [ctypes.POINTER(_vp), _vp, ctypes.c_long, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, _vp]
+        L.pda_peer_allreduce.restype = ctypes.c_int
+        L._peer_ready = True
+    return L
+
+
+def plan(numel, world):
+    """(slice, chunk, chunks per slice) the kernel uses for `numel` elements over `world` ranks."""
+    L = _lib()
+    sl, ch, n = ctypes.c_long(), ctypes.c_long(), ctypes.c_int()
+    L.pda_peer_plan(int(numel), int(world), ctypes.byref(sl), ctypes.byref(ch), ctypes.byref(n))
+    return sl.value, ch.value, n.value
+
+
+class PeerAllReduce(object):
+    """In-place SUM all-reduce of ONE fixed fp32 device buffer of `numel` elements over the ranks of `comm`
+    (a TorchComm: used only to exchange the 64-byte IPC handles).  wire="bf16" sends slices as bf16."""
+
+    def __init__(self, comm, numel, device, wire="fp32"):
+        self.comm, self.numel, self.device = comm, int(numel), torch.device(device)
+        self.rank, self.world = int(comm.rank), int(comm.world_size)
+        if not 2 <= self.world <= MAX_RANKS:
+            raise ValueError("peer all-reduce serves 2..%d ranks, not %d" % (MAX_RANKS, self.world))
+        if wire not in ("fp32", "bf16"):
+            raise ValueError("wire must be 'fp32' or 'bf16'")
+        self.wire_bf16 = 1 if wire == "bf16" else 0
+        self.local, self.peers, self.closed = None, {}, False
+        L = _lib()
+        torch.cuda.set_device(self.device)
+        nbytes = L.pda_peer_region_bytes(self.numel, self.world, self.wire_bf16)
+        ptr, handle = _vp(), ctypes.create_string_buffer(64)
+        rc = L.pda_peer_alloc(nbytes, ctypes.byref(ptr), handle)
+        mine = {"rank": self.rank, "rc": int(rc), "handle": handle.raw if rc == 0 else b"", "pid": os.getpid(),
+                "bytes": int(nbytes)}
+        if rc == 0:
+            self.local = ptr.value
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=getattr(comm, "group", None))
+        err = None
+        if any(e["rc"] != 0 for e in everyone):
+            err = "hipExtMallocWithFlags / hipIpcGetMemHandle failed on ranks %s" % [e["rank"] for e in everyone if e["rc"]]
+        regions = [0] * self.world
+        if err is None:
+            for e in everyone:
+                if e["rank"] == self.rank:
+                    regions[e["rank"]] = self.local
+                    continue
+                p = _vp()
+                rc = L.pda_peer_open(e["handle"], ctypes.byref(p))
+                if rc != 0:
+                    err = "hipIpcOpenMemHandle(rank %d) failed with hipError %d on rank %d" % (e["rank"], rc, self.rank)
+                    break
+                self.peers[e["rank"]] = p.value
+                regions[e["rank"]] = p.value
+        # every rank must know whether every OTHER rank mapped its peers: decide together
+        status = [None] * self.world
+        dist.all_gather_object(status, err, group=getattr(comm, "group", None))
+        bad = [s for s in status if s]
+        if bad:
+            self.close()
+            raise RuntimeError("peer all-reduce unavailable: " + "; ".join(bad))
+        self.regions = (_vp * self.world)(*regions)
+
+    def all_reduce_sum_(self, flat):
+        """Enqueue the all-reduce of `flat` (fp32, contiguous, 16-byte aligned, numel as constructed) on the
+        current stream.  No host synchronisation: safe inside stream capture."""
+        assert flat.dtype == torch.float32 and flat.is_contiguous() and flat.numel() == self.numel
+        assert flat.data_ptr() % 16 == 0, "gradient bucket must start on a 16-byte boundary"
+        rc = _lib().pda_peer_allreduce(self.regions, _vp(flat.data_ptr()), self.numel, self.rank, self.world,
+                                       self.wire_bf16, _vp(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError("peer all-reduce launch failed: hipError %d" % rc)
+        return flat
+
+    def error(self):
+        """0, or the code of the wait that timed out ((phase << 8) | awaited rank).  Synchronises the device."""
+        return int(_lib().pda_peer_error(_vp(self.local))) if self.local else -1
+
+    def close(self):
+        if self.closed:
+            return
+        self.closed = True
+        L = _lib()
+        try:
+            torch.cuda.synchronize(self.device)
+        except Exception:
+            pass
+        for p in self.peers.values():
+            L.pda_peer_close(_vp(p))
+        self.peers = {}
+        if self.local:
+            L.pda_peer_free(_vp(self.local))
+            self.local = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _RcclAllReduce(object):
+    kind = "rccl"
+
+    def __init__(self, comm):
+        self.comm = comm
+
+    def all_reduce_sum_(self, flat):
+        return self.comm.all_reduce_sum_(flat)
+
+    def close(self):
+        pass
+
+
+def self_test(peer, comm, device):
+    """One real all-reduce of rank-dependent values through `peer`, checked on every rank; all ranks agree
+    on the verdict.  The kernel's waits are bounded, so a broken mapping fails here instead of hanging."""
+    n = peer.numel
+    buf = torch.arange(n, device=device, dtype=torch.float32).remainder_(97.0).add_(float(peer.rank + 1))
+    want = torch.arange(n, device=device, dtype=torch.float32).remainder_(97.0).mul_(float(peer.world)) \
+        .add_(float(peer.world * (peer.world + 1) // 2))
+    peer.all_reduce_sum_(buf)
+    peer.all_reduce_sum_(buf.copy_(torch.arange(n, device=device, dtype=torch.float32).remainder_(97.0)
+                                   .add_(float(peer.rank + 1))))       # twice: the epoch hand-over
+    torch.cuda.synchronize(device)
+    tol = 0.0 if not peer.wire_bf16 else 0.02 * float(want.abs().max().item())
+    ok = peer.error() == 0 and float((buf - want).abs().max().item()) <= tol
+    return comm.all_agree(ok)
+
+
+def make_grad_allreduce(comm, flat, kind=None, wire="fp32"):
+    """The all-reduce object (`.all_reduce_sum_(flat)`, `.kind`) for one gradient bucket."""
+    kind = (kind or os.environ.get("PDA_DP_ALLREDUCE", "auto")).lower()
+    gpu_group = (comm is not None and getattr(comm, "world_size", 1) > 1 and flat.is_cuda and dist is not None
+                 and dist.is_initialized())
+    if kind == "rccl" or not gpu_group:
+        if kind == "peer":
+            raise RuntimeError("peer all-reduce needs a multi-rank process group and a GPU buffer")
+        return _RcclAllReduce(comm)
+    try:
+        if not comm.all_agree(flat.data_ptr() % 16 == 0):
+            raise RuntimeError("gradient bucket not 16-byte aligned on every rank")
+        peer = PeerAllReduce(comm, flat.numel(), flat.device, wire=wire)
+        if not self_test(peer, comm, flat.device):      # (collective verdict: the same on every rank)
+            peer.close()
+            raise RuntimeError("peer all-reduce self-test failed")
+    except (RuntimeError, ValueError, OSError) as exc:
+        if kind == "peer":
+            raise
+        if getattr(comm, "rank", 0) == 0:
+            print("[peer-allreduce] falling back to %s: %s" % (getattr(comm, "backend", "the process group"), exc),
+                  flush=True)
+        return _RcclAllReduce(comm)
+    peer.kind = "peer-%s" % wire
+    return peer
+
+
+# ---- multi-process check: N ranks, all on one GPU or one each -----------------------------------------------------
+def _worker():
+    """`python -m pytorch_distributed_amd.parallel.peer_allreduce`: RANK / WORLD_SIZE / MASTER_PORT from the
+    environment; PDA_PEER_SHARE_GPU=1 puts every rank on cuda:0 (the kernel is then exercised across PROCESSES
+    on a one-GPU box: peer regions are IPC mappings either way).  Prints one JSON line per rank."""
+    import json
+    import time
+    from .comm import TorchComm
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    share = os.environ.get("PDA_PEER_SHARE_GPU", "0") == "1"
+    dev = torch.device("cuda:%d" % (0 if share else rank))
+    torch.cuda.set_device(dev)
+    backend = os.environ.get("PDA_PEER_BACKEND", "gloo" if share else "nccl")
+    comm = TorchComm(rank, world, dev, init_method="tcp://127.0.0.1:%s" % os.environ.get("MASTER_PORT", "29611"),
+                     backend=backend, timeout_s=120)
+    out = {"rank": rank, "world": world, "cases": []}
+    ok_all = True
+    for numel, wire in ((1000, "fp32"), (77984, "fp32"), (1609222, "fp32"), (1687206, "fp32"), (1609222, "bf16")):
+        peer = PeerAllReduce(comm, numel, dev, wire=wire)
+        g = torch.Generator(device=dev).manual_seed(1234 + 17 * rank)
+        x = torch.randn(numel, device=dev, generator=g)
+        ref = x.clone()
+        comm.all_reduce_sum_(ref)                    # the process group's own sum
+        got = x.clone()
+        peer.all_reduce_sum_(got)
+        torch.cuda.synchronize(dev)
+        tol = (1e-6 if wire == "fp32" else 2e-2) * float(ref.abs().max().item())
+        err = float((got - ref).abs().max().item())
+        # every rank must hold the SAME bits: compare with rank 0's result
+        r0 = got.clone()
+        comm.broadcast_(r0, src=0)
+        same = bool(torch.equal(r0, got))
+        # back-to-back calls with no host synchronisation in between, then the same calls replayed from a graph
+        y = torch.empty_like(x)
+        for _ in range(10):
+            y.copy_(x)
+            peer.all_reduce_sum_(y)
+        torch.cuda.synchronize(dev)
+        chained = bool(torch.equal(y, got))
+        side = torch.cuda.Stream(device=dev)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            y.copy_(x)
+            peer.all_reduce_sum_(y)             # warm: nothing lazy inside the capture
+            side.synchronize()
+            with torch.cuda.graph(gr, stream=side, capture_error_mode="thread_local"):
+                y.copy_(x)
+                peer.all_reduce_sum_(y)
+        comm.barrier()
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            gr.replay()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / reps
+        graphed = bool(torch.equal(y, got))
+        case = {"numel": numel, "wire": wire, "max_err_vs_group_sum": err, "tol": tol, "same_bits_on_all_ranks": same,
+                "chained_calls_ok": chained, "graph_replay_ok": graphed, "us_per_call_in_graph": round(1e6 * dt, 1),
+                "kernel_error_word": peer.error(), "plan": plan(numel, world)}
+        good = err <= tol and same and chained and graphed and case["kernel_error_word"] == 0
+        ok_all = ok_all and comm.all_agree(good)
+        out["cases"].append(case)
+        peer.close()
+    out["ok"] = ok_all
+    print(json.dumps(out), flush=True)
+    comm.close()
+    return 0 if ok_all else 1
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(_worker())

@@ -37,3 +37,28 @@ def test_two_rank_dp_bench_keeps_ranks_identical():
     assert res["dp_param_max_abs_diff_across_ranks"] == 0.0
     assert res["rccl_ranks"] == 2 and res["ranks_distinct"] is True and res["rank_id_min_max_sum"] == [0, 1, 1]
     assert res["final_loss"] == res["final_loss"] and res["value"] > 0      # finite
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_two_rank_dp_with_the_peer_allreduce_in_one_graph(precision):
+    """Same rehearsal with the xGMI peer all-reduce kernel (hipIpc-mapped regions, ops/csrc/peer_allreduce.hip):
+    nothing host-driven is left in the step, so five whole data-parallel updates -- collectives included -- replay as
+    ONE hipGraph even though the process group is gloo."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PDA_DP_GRAPH", "PDA_DP_ALLREDUCE"):
+        env.pop(k, None)
+    env["PDA_BENCH_FAULTHANDLER"] = "100"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5",
+           "--backend", "gloo", "--share-gpu", "--replay", "4096", "--min-time", "0", "--precision", precision,
+           "--allreduce", "peer", "--launch-timeout", "100"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=115)
+    assert out.returncode == 0, out.stderr.decode(errors="replace")[-2000:]
+    res = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 2 and res["config"]["engine"] == "DqnNativeCore" and res["config"]["precision"] == precision
+    assert res["dp_allreduce"] == "peer-fp32" and res["dp_graph"] == "whole"
+    assert res["config"]["steps_per_graph"] == 5
+    assert res["dp_param_max_abs_diff_across_ranks"] == 0.0
+    assert res["ranks_distinct"] is True
+    assert res["final_loss"] == res["final_loss"] and res["value"] > 0
+    print(json.dumps({k: res[k] for k in ("value", "ms_per_step", "dp_allreduce", "dp_graph")}))
