@@ -308,6 +308,21 @@ struct EpiAtomicF32 {   // split-K partial sums: atomicAdd acc into fp32 out[m*l
     __device__ __forceinline__ void bias_grad(int, float, int) const {}
 };
 
+// split-K partial sums with plain stores: slice y of the reduction writes its tile to out + y * slice_stride.
+// The consumer adds the slices in a fixed order, so the result is bit-reproducible (fp32 atomics arrive in any
+// order) and nothing has to be zeroed between steps.
+struct EpiSlabF32 {
+    float* out; long ld; long slice_stride;
+    static constexpr bool kBiasGrad = false;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N) const {
+        if (n >= N) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (m + r < M) out[(long)(m + r) * ld + n] = v[r];
+    }
+    __device__ __forceinline__ void bias_grad(int, float, int) const {}
+};
+
 struct EpiMaskBf16 {    // dgrad: out = acc * act'(y[m][n]) -> bf16 ; y is the forward output
     bf16_t* out; const bf16_t* y; int act; long ld; long ldy; long plane;
     static constexpr bool kBiasGrad = false;
@@ -376,6 +391,11 @@ struct EpiWgrad {
 // the epilogue of split-K slice `by` (the slice index is an argument, not blockIdx.y: launches that carry
 // several kernels' workgroups decode their own linear block index)
 template <class EP> __device__ __forceinline__ EP epi_for_slice(const EP& e, int) { return e; }
+__device__ __forceinline__ EpiSlabF32 epi_for_slice(const EpiSlabF32& e, int by) {
+    EpiSlabF32 r = e;
+    r.out += (long)by * e.slice_stride;
+    return r;
+}
 __device__ __forceinline__ EpiWgrad epi_for_slice(const EpiWgrad& e, int by) {
     EpiWgrad r = e;
     r.gw += (long)by * e.slice_stride;

@@ -99,6 +99,26 @@ PDA_EXPORT void pda_linear_fwd(const void* const* x, const void* const* w, const
     else launch_gemm<64, 64, 2, 2>(a, ngroups, M, N, K, 0, stream);
 }
 
+// ---- linear forward, split-K into slabs: slice y of group g -> out32[g] + y * slice_stride (plain stores) --------
+// For fc1 of the learner step: the head kernel adds the slices in order (bit-reproducible, no atomics, nothing to
+// zero).  Workgroups run in XCD-aware order: all tiles of one (slice, group) unit share one XCD's L2, so the launch
+// fetches its operand rows from HBM once instead of once per XCD (plain order: 18.5 MB per launch at 23 % L2 hits).
+PDA_EXPORT void pda_linear_fwd_slab(const void* const* x, const void* const* w, void* const* out32, int ngroups,
+                                    int M, int N, int K, long ldx, long ldw, long ldo32, long slice_stride,
+                                    int ksplit, hipStream_t stream) {
+    GemmArgs<SrcDenseK, SrcDenseK, EpiSlabF32> a;
+    for (int i = 0; i < ngroups; ++i) {
+        a.g[i].a = {(const bf16_t*)x[i], ldx, M, K};
+        a.g[i].b = {(const bf16_t*)w[i], ldw, N, K};
+        a.g[i].e = {(float*)out32[i], ldo32, slice_stride};
+        a.g[i].M = M; a.g[i].N = N; a.g[i].K = K;
+    }
+    int3 grid = plan_gemm<64, 64>(a, ngroups, M, N, K, ksplit > 0 ? ksplit : K);
+    int units = grid.y * grid.z;
+    hipLaunchKernelGGL((gemm_xcd_kernel<64, 64, 2, 2, GEMM_BK, SrcDenseK, SrcDenseK, EpiSlabF32>),
+                       dim3((units + 7) / 8 * 8 * grid.x), dim3(GEMM_THREADS), 0, stream, a, grid);
+}
+
 // ---- data gradient of a linear map: dx[M][Kin] = (dy[M][Nout] * w[Nout][Kin]) * act'(y) ------
 // Also the "dcol" half of a conv data gradient (y == null: no mask).
 PDA_EXPORT void pda_linear_dgrad(const void* dy, const void* w, const void* y, void* dx, int M, int Nout, int Kin,

@@ -69,11 +69,27 @@ PDA_EXPORT void pda_x3_conv_fwd(const void* const* x, long x_plane, const void* 
 
 // ---- linear forward, split-K: partial sums into fp32 out32 -------------------------------------------
 // slice_stride == 0: atomically added into out32 (pre-zeroed).  slice_stride > 0: slice y goes to
-// out32 + y * slice_stride with plain stores (deterministic; the consumer sums the slices).
+// out32 + y * slice_stride with plain stores, XCD-ordered (deterministic; the consumer sums the slices).
 PDA_EXPORT void pda_x3_linear_fwd(const void* const* x, long x_plane, const void* const* w, long w_plane,
                                   void* const* out32, int ngroups, int M, int N, int K, long ldx, long ldw,
-                                  long ldo32, int ksplit, hipStream_t stream) {
-    GemmArgs<SPLIT_A3(SrcDenseK), SPLIT_B3(SrcDenseK), EpiAtomicF32> a;
+                                  long ldo32, long slice_stride, int ksplit, hipStream_t stream) {
+    typedef SPLIT_A3(SrcDenseK) SA;
+    typedef SPLIT_B3(SrcDenseK) SB;
+    if (slice_stride > 0) {
+        GemmArgs<SA, SB, EpiSlabF32> a;
+        for (int i = 0; i < ngroups; ++i) {
+            a.g[i].a = {{(const bf16_t*)x[i], ldx, M, K}, x_plane, K};
+            a.g[i].b = {{(const bf16_t*)w[i], ldw, N, K}, w_plane, K};
+            a.g[i].e = {(float*)out32[i], ldo32, slice_stride};
+            a.g[i].M = M; a.g[i].N = N; a.g[i].K = 3 * K;
+        }
+        int3 grid = plan_gemm<64, 64>(a, ngroups, M, N, 3 * K, ksplit > 0 ? ksplit : 3 * K);
+        int units = grid.y * grid.z;
+        hipLaunchKernelGGL((gemm_xcd_kernel<64, 64, 2, 2, GEMM_BK, SA, SB, EpiSlabF32>),
+                           dim3((units + 7) / 8 * 8 * grid.x), dim3(GEMM_THREADS), 0, stream, a, grid);
+        return;
+    }
+    GemmArgs<SA, SB, EpiAtomicF32> a;
     for (int i = 0; i < ngroups; ++i) {
         a.g[i].a = {{(const bf16_t*)x[i], ldx, M, K}, x_plane, K};
         a.g[i].b = {{(const bf16_t*)w[i], ldw, N, K}, w_plane, K};

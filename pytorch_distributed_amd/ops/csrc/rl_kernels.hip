@@ -28,6 +28,9 @@ struct DqnHeadArgs {
     unsigned long long* rng_counter; int* opt_step;     // bumped here (nobody reads them in this launch)
     // fp32-precision learner: element offsets to the lo planes of the split-bf16 outputs (0: plain bf16 outputs)
     long h1_plane, dh1_plane, dq_plane;
+    // fc1 split-K sums delivered as slabs (pda_linear_fwd_slab): h1pre_*[s * h1_slice_stride + ...], s < h1_slices,
+    // added here in slice order; 0 = one atomically accumulated buffer that this kernel zeroes after reading
+    int h1_slices; long h1_slice_stride;
 };
 
 template <int HID>
@@ -60,14 +63,32 @@ __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
     }
 
     float h0[PER], ht[PER], hd[PER];
+    if (p.h1_slices > 0) {
+        // slabs: PER consecutive floats per lane and slice (16-byte loads), summed in slice order
+        typedef float vecf __attribute__((ext_vector_type(PER)));
+        vecf a0 = {}, at = {}, ad = {};
+        for (int sl = 0; sl < p.h1_slices; ++sl) {
+            const long o = (long)sl * p.h1_slice_stride + row;
+            a0 += *reinterpret_cast<const vecf*>(p.h1pre_on0 + o);
+            at += *reinterpret_cast<const vecf*>(p.h1pre_tg1 + o);
+            if (p.h1pre_on1) ad += *reinterpret_cast<const vecf*>(p.h1pre_on1 + o);
+        }
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        h0[j] = fmaxf(p.h1pre_on0[row + j] + p.b4_on[lane * PER + j], 0.f);
-        ht[j] = fmaxf(p.h1pre_tg1[row + j] + p.b4_tg[lane * PER + j], 0.f);
-        hd[j] = p.h1pre_on1 ? fmaxf(p.h1pre_on1[row + j] + p.b4_on[lane * PER + j], 0.f) : 0.f;
-        p.h1pre_on0[row + j] = 0.f;
-        p.h1pre_tg1[row + j] = 0.f;
-        if (p.h1pre_on1) p.h1pre_on1[row + j] = 0.f;
+        for (int j = 0; j < PER; ++j) {
+            h0[j] = fmaxf(a0[j] + p.b4_on[lane * PER + j], 0.f);
+            ht[j] = fmaxf(at[j] + p.b4_tg[lane * PER + j], 0.f);
+            hd[j] = p.h1pre_on1 ? fmaxf(ad[j] + p.b4_on[lane * PER + j], 0.f) : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            h0[j] = fmaxf(p.h1pre_on0[row + j] + p.b4_on[lane * PER + j], 0.f);
+            ht[j] = fmaxf(p.h1pre_tg1[row + j] + p.b4_tg[lane * PER + j], 0.f);
+            hd[j] = p.h1pre_on1 ? fmaxf(p.h1pre_on1[row + j] + p.b4_on[lane * PER + j], 0.f) : 0.f;
+            p.h1pre_on0[row + j] = 0.f;
+            p.h1pre_tg1[row + j] = 0.f;
+            if (p.h1pre_on1) p.h1pre_on1[row + j] = 0.f;
+        }
     }
 
     // lane a keeps q(.)[a]: no runtime-indexed arrays (they would live in scratch).  Actions go in

@@ -59,7 +59,8 @@ class _HeadArgs(ctypes.Structure):     # mirrors DqnHeadArgs in csrc/rl_kernels.
                 ("leaf_sum", _vp), ("leaf_min", _vp), ("prio_eps", ctypes.c_float), ("prio_alpha", ctypes.c_float),
                 ("B", ctypes.c_int), ("HID", ctypes.c_int), ("A", ctypes.c_int),
                 ("rng_counter", _vp), ("opt_step", _vp),
-                ("h1_plane", ctypes.c_long), ("dh1_plane", ctypes.c_long), ("dq_plane", ctypes.c_long)]
+                ("h1_plane", ctypes.c_long), ("dh1_plane", ctypes.c_long), ("dq_plane", ctypes.c_long),
+                ("h1_slices", ctypes.c_int), ("h1_slice_stride", ctypes.c_long)]
 
 
 class _ActArgs(ctypes.Structure):      # mirrors ActHeadArgs
@@ -233,6 +234,7 @@ class _Acts(object):
         self.a2 = [z(B * g.H2 * g.W2, 64) for _ in range(groups)]
         self.a3 = [z(B * g.P3, 64) for _ in range(groups)]
         self.h1pre = [z(B, g.HID, dtype=torch.float32) for _ in range(groups)]
+        self.h1_slices, self.h1_ksplit = 0, 0       # > 0: fc1's split-K sums arrive as slabs (fc1_slabs below)
         if backward:
             self.h1 = z(B, g.HID)
             self.dh1 = z(B, g.HID)
@@ -276,6 +278,10 @@ def cnn_forward(geom, nets, frames, idxs, acts, B, norm_val, keep_first_only=Tru
                        4, 4, 2, 64)
         nn.x3_conv_fwd(acts.a2[:n], [w.w[2] for w in nets], [w.b[2] for w in nets], acts.a3[:n], B, g.H2, g.W2, 64,
                        3, 3, 1, 64)
+        if acts.h1_slices:
+            nn.x3_linear_fwd(acts.a3[:n], [w.w[3] for w in nets], acts.h1pre[:n], B, g.HID, g.F, g.F, g.F, g.HID,
+                             ksplit=acts.h1_ksplit, slice_stride=B * g.HID)
+            return
         tiles = ((B + 63) // 64) * (g.HID // 64) * n
         nn.x3_linear_fwd(acts.a3[:n], [w.w[3] for w in nets], acts.h1pre[:n], B, g.HID, g.F, g.F, g.F, g.HID,
                          ksplit=_ksplit(3 * g.F, tiles, _FC1_BLOCKS, 128))
@@ -293,9 +299,25 @@ def cnn_forward(geom, nets, frames, idxs, acts, B, norm_val, keep_first_only=Tru
                        g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / float(norm_val))
         nn.conv_fwd(acts.a1[:n], [w.w[1] for w in nets], [w.b[1] for w in nets], acts.a2[:n], B, g.H1, g.W1, 32, 4, 4, 2, 64)
         nn.conv_fwd(acts.a2[:n], [w.w[2] for w in nets], [w.b[2] for w in nets], acts.a3[:n], B, g.H2, g.W2, 64, 3, 3, 1, 64)
+    if acts.h1_slices:
+        nn.linear_fwd_slab(acts.a3[:n], [w.w[3] for w in nets], acts.h1pre[:n], B, g.HID, g.F, g.F, g.F, g.HID,
+                           B * g.HID, acts.h1_ksplit)
+        return
     tiles = ((B + 63) // 64) * (g.HID // 64) * n
     nn.linear_fwd(acts.a3[:n], [w.w[3] for w in nets], None, None, acts.h1pre[:n], B, g.HID, g.F, g.F, g.F,
                   0, g.HID, ksplit=_ksplit(g.F, tiles, _FC1_BLOCKS, 128))
+
+
+def fc1_slabs(acts, geom, B, groups, device):
+    """Switch fc1's forward split-K from fp32 atomics into one buffer to slabs [slices][B][HID] per network that
+    the head kernel adds in slice order: bit-reproducible steps, no memory-side atomics, nothing to zero."""
+    g = geom
+    mult = 3 if acts.split else 1
+    tiles = ((B + 63) // 64) * (g.HID // 64) * groups
+    ks = _ksplit(mult * g.F, tiles, _FC1_BLOCKS, 128)
+    acts.h1_ksplit = ks
+    acts.h1_slices = nn.num_slices(mult * g.F, ks)
+    acts.h1pre = [torch.zeros(acts.h1_slices, B, g.HID, dtype=torch.float32, device=device) for _ in range(groups)]
 
 
 class DqnCnnEngine(object):
@@ -325,6 +347,11 @@ class DqnCnnEngine(object):
                              clip=clip, shadow=self.online.shadow, shadow_plane=self.online.shadow_plane)
         self.groups = 3 if self.double else 2
         self.acts = _Acts(g, self.B, self.groups, dev, backward=True, split=x3)
+        # fc1 forward split-K as slabs summed by the head kernel: makes two runs of a step program bit-identical
+        # (the last source of run-to-run differences was the arrival order of fc1's fp32 atomics)
+        if os.environ.get("PDA_FC1_SLAB", "1") != "0":
+            fc1_slabs(self.acts, g, self.B, self.groups, dev)
+        self.deterministic = self.acts.h1_slices > 0
         self.pair_wgrad = (bool(self.acts.stack_dgrad) or x3) and os.environ.get("PDA_PAIR_WGRAD", "1") != "0"
         # large batches: conv2 + conv3 weight gradients per image with register accumulation (csrc/conv1_kernels.hip)
         self.stack_wgrad = bool(self.acts.stack_dgrad) and self.B >= _WGRAD_STACK_MIN and not x3
@@ -466,7 +493,8 @@ class DqnCnnEngine(object):
             prio_alpha=float(self.per["alpha"]) if self.per else 1.0,
             B=B, HID=g.HID, A=g.A, rng_counter=_p(self.counter), opt_step=_p(self.adam.step_dev),
             h1_plane=getattr(a.h1, "plane", 0), dh1_plane=getattr(a.dh1, "plane", 0),
-            dq_plane=getattr(a.dq, "plane", 0))
+            dq_plane=getattr(a.dq, "plane", 0),
+            h1_slices=a.h1_slices, h1_slice_stride=B * g.HID)
         _L().pda_dqn_head(ctypes.byref(args), _stream())
 
     @staticmethod

@@ -188,6 +188,20 @@ def linear_fwd(x, w, bias, out, out32, M, N, K, ldx, ldw, ldo=0, ldo32=0, act=AC
                         _stream())
 
 
+def linear_fwd_slab(x, w, out32, M, N, K, ldx, ldw, ldo32, slice_stride, ksplit):
+    """Split-K linear forward into slabs: slice y of group g -> out32[g] + y * slice_stride elements, plain stores,
+    XCD-ordered launch.  num_slices(K, ksplit) slices; the consumer sums them (csrc/rl_kernels.hip: dqn_head)."""
+    assert ldx % 8 == 0 and ldw % 8 == 0 and len(x) <= GEMM_MAX_GROUPS and slice_stride >= M * ldo32
+    L = _L()
+    if not getattr(L, "_fwd_slab_ready", False):
+        c_int, c_long = ctypes.c_int, ctypes.c_long
+        L.pda_linear_fwd_slab.argtypes = [_vp] * 3 + [c_int] * 4 + [c_long] * 4 + [c_int, _vp]
+        L.pda_linear_fwd_slab.restype = None
+        L._fwd_slab_ready = True
+    L.pda_linear_fwd_slab(_arr(x), _arr(w), _arr(out32), len(x), M, N, K, ldx, ldw, ldo32, int(slice_stride),
+                          int(ksplit), _stream())
+
+
 def linear_dgrad(dy, w, y, dx, M, Nout, Kin, lddy, ldw, ldy, lddx, act=ACT_NONE):
     """dx[M][Kin] = (dy[M][Nout] @ w[Nout][Kin]) * act'(y[M][Kin]) (y None: no mask).
     Nout / Kin need not be multiples of 8 when the pad columns of dy (inside lddy) are zero
@@ -433,7 +447,7 @@ def _X():
         c_int, c_long, c_float = ctypes.c_int, ctypes.c_long, ctypes.c_float
         L.pda_x3_conv_fwd_u8.argtypes = [_vp] * 3 + [c_long, _vp, _vp, c_long] + [c_int] * 9 + [c_float, c_int, _vp]
         L.pda_x3_conv_fwd.argtypes = [_vp, c_long, _vp, c_long, _vp, _vp, c_long] + [c_int] * 10 + [_vp]
-        L.pda_x3_linear_fwd.argtypes = [_vp, c_long, _vp, c_long, _vp] + [c_int] * 4 + [c_long] * 3 + [c_int, _vp]
+        L.pda_x3_linear_fwd.argtypes = [_vp, c_long, _vp, c_long, _vp] + [c_int] * 4 + [c_long] * 4 + [c_int, _vp]
         L.pda_x3_linear_dgrad.argtypes = ([_vp, c_long, _vp, c_long, _vp, _vp, c_long] + [c_int] * 3 + [c_long] * 4 +
                                           [c_int, _vp])
         L.pda_x3_conv_dgrad.argtypes = [_vp, c_long, _vp, c_long, _vp, _vp, c_long] + [c_int] * 9 + [_vp]
@@ -478,11 +492,12 @@ def x3_conv_fwd(x, w, bias, out, batch, H, W, C, KH, KW, S, O, act=ACT_RELU):
                          len(x), batch, H, W, C, KH, KW, S, O, act, _stream())
 
 
-def x3_linear_fwd(x, w, out32, M, N, K, ldx, ldw, ldo32, ksplit=0):
-    """Split-K partial sums atomically added into the fp32 out32 (pre-zeroed); ksplit counts the 3 K reduction."""
+def x3_linear_fwd(x, w, out32, M, N, K, ldx, ldw, ldo32, ksplit=0, slice_stride=0):
+    """Split-K partial sums over the 3 K reduction (ksplit counts it): atomically added into the fp32 out32
+    (pre-zeroed), or -- slice_stride > 0 -- written as slabs, slice y at out32 + y * slice_stride."""
     assert K % 8 == 0 and ldx % 8 == 0 and ldw % 8 == 0 and len(x) <= GEMM_MAX_GROUPS
     _X().pda_x3_linear_fwd(_arr(x), _same_plane(x), _arr(w), _same_plane(w), _arr(out32), len(x), M, N, K, ldx, ldw,
-                           ldo32, int(ksplit), _stream())
+                           ldo32, int(slice_stride), int(ksplit), _stream())
 
 
 def x3_linear_dgrad(dy, w, y, dx, M, Nout, Kin, lddy, ldw, ldy, lddx, act=ACT_NONE):
