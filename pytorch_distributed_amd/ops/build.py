@@ -17,8 +17,11 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libpda_hip.so")
 ARCH = "gfx950"
+# -ffast-math for reassociation / approximate transcendentals, but NOT finite-math-only: kernels use +-INFINITY as
+# real values (arg-max sentinels in rl_kernels.hip, +inf leaves of the min tree), which finite-math-only would make
+# undefined behaviour.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-gpu-rdc", "-fvisibility=hidden",
-         "-Wall", "-Wno-unused-function", "-ffast-math"]
+         "-Wall", "-Wno-unused-function", "-ffast-math", "-fno-finite-math-only"]
 
 
 def _hipcc():
@@ -35,7 +38,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+LAST_REPORT = {}       # source basename -> "compiled" | "reused" for the most recent build() (+ "link")
+
+
 def build(force=False, verbose=False, extra_flags=()):
+    """Compile what is stale (everything with force=True, or PDA_BUILD_FORCE=1) and link.  LAST_REPORT says, per
+    object, whether it was compiled from source in this call or reused from an earlier one."""
+    force = force or os.environ.get("PDA_BUILD_FORCE", "0") == "1"
+    LAST_REPORT.clear()
     os.makedirs(OBJ_DIR, exist_ok=True)
     sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     headers = sorted(glob.glob(os.path.join(CSRC, "*.h")))
@@ -46,8 +56,17 @@ def build(force=False, verbose=False, extra_flags=()):
     for src in sources:
         obj = os.path.join(OBJ_DIR, os.path.basename(src).replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + headers):
+        # (the flags are part of the recipe: an object built with other flags is stale too)
+        stamp = obj + ".flags"
+        flags = " ".join(FLAGS + list(extra_flags))
+        same_flags = os.path.exists(stamp) and open(stamp).read() == flags
+        if force or not same_flags or _stale(obj, [src] + headers):
             jobs.append([hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj])
+            LAST_REPORT[os.path.basename(src)] = "compiled"
+            if os.path.exists(stamp):
+                os.remove(stamp)
+        else:
+            LAST_REPORT[os.path.basename(src)] = "reused"
 
     def run(cmd):
         if verbose:
@@ -60,6 +79,10 @@ def build(force=False, verbose=False, extra_flags=()):
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as pool:
         list(pool.map(run, jobs))
+    for cmd in jobs:
+        with open(cmd[-1] + ".flags", "w") as fh:
+            fh.write(" ".join(FLAGS + list(extra_flags)))
+    LAST_REPORT["link"] = "linked" if (force or jobs or _stale(LIB, objs)) else "reused"
     if force or jobs or _stale(LIB, objs):
         tmp = LIB + ".tmp%d" % os.getpid()
         run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp] + objs + ["-lpthread"])
@@ -69,4 +92,4 @@ def build(force=False, verbose=False, extra_flags=()):
 
 if __name__ == "__main__":
     path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
-    print("built", path)
+    print("built", path, LAST_REPORT)

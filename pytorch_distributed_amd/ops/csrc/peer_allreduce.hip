@@ -4,39 +4,45 @@
 // (utils/helpers.py:28-34 ensure_global_grads, commented out at core/single_processes/dqn_learner.py:85-86) never
 // ran.  Here learners are synchronous data-parallel ranks, one process per MI355X, and what they exchange every
 // ~80 us of compute is one 6.75 MB gradient.  A ring all-reduce moves that over ONE outgoing link per GPU in
-// 2(N-1) dependent hops; MI355X nodes are fully connected (7 links x ~153 GB/s per GPU), so this kernel uses all
-// links at once and is two hops deep:
+// 2(N-1) dependent hops; MI355X nodes are fully connected (7 links per GPU), so this kernel uses all links at once
+// and is two hops deep:
 //
-//   phase 1  scatter   rank r stores slice p of its gradient into rank p's staging area, slot r  (p != r; N-1
-//                      links busy at once), then raises flag1[r][chunk] in rank p's memory
-//   phase 2  reduce    rank r sums its own slice over the N slots in rank order (every rank reduces ONE slice, so
-//                      the result is bit-identical everywhere) and stores the sum into every rank's result area,
-//                      then raises flag2[r][chunk][sub]
-//   phase 3  gather    every rank copies the N reduced slices from its result area into its gradient buffer
+//   phase 1  scatter   rank r stores slice p of its gradient into rank p's staging area, slot r (p != r: N-1 links
+//                      busy at once)
+//   phase 2  reduce    rank r sums its own slice over the N slots IN RANK ORDER (every rank reduces one slice, so the
+//                      result is bit-identical everywhere), writes it into its gradient buffer and stores it into
+//                      every peer's result area
+//   phase 3  gather    every rank copies the N-1 reduced peer slices from its result area into its gradient buffer
 //
-// All hand-off memory (staging, result, flags) is one uncached (fine-grained, MTYPE_UC) allocation per rank,
-// exported with hipIpcGetMemHandle and mapped by every peer: uncached accesses bypass the per-XCD L2s on both
-// sides, so a consumer never holds a stale line and a producer needs no write-back -- only a system-scope fence
-// between its data stores and its flag store.  Flags carry a monotonically increasing epoch that the kernel itself
-// reads and bumps in device memory, so the launch takes no per-call argument and replays inside a hipGraph.
-// Work is dealt as (peer p, chunk j) to N x CH workgroups which all stay resident (<= 256 of 256 threads), every
-// spin is bounded (a timeout raises an error word instead of hanging the GPU), and no workgroup ever waits on
-// another workgroup of its own GPU, only on flags stored by peers.
-// Optional bf16 wire format: slices cross the links as bf16 (converted while being stored: no conversion launches)
-// and are summed in fp32; the reducing rank rounds its sum through bf16 as well, so all ranks still end up with
-// identical gradients.
+// Hand-off protocol: the data IS the flag.  Everything that crosses processes travels as naturally aligned 8-byte
+// granules {payload, tag = epoch of this call}, written by ONE store instruction each (two granules per 16-byte
+// write-through store) and polled by the consumer until the tag matches -- no separate flag word whose store could
+// be observed before the data it covers, no fences, no barriers.  (A first version used flag words behind
+// release / acquire fences, exactly as within one process; across processes it delivered, only under load, a few
+// 128-byte lines per call whose data arrived after their flag -- found by the multi-process test, which checks every
+// element.)  A granule of an earlier call carries an older tag and reads as "not yet"; epochs of different regions
+// never meet (pda_peer_alloc: epoch_base).  The epoch is read and bumped by the kernel itself in device memory, so
+// the launch takes no per-call argument and replays inside a hipGraph.
+// All hand-off memory is one uncached allocation per rank, exported with hipIpcGetMemHandle and mapped by every
+// peer; it is only ever touched by system-scope accesses (sc0 sc1: write-through stores, cache-missing loads).
+// Work is dealt as (peer p, chunk j) to N x CH workgroups that all stay resident (<= 224 of 256 threads), every spin
+// is bounded (a timeout raises an error word instead of hanging the GPU), and a wait only ever depends on PEERS'
+// stores, never on another workgroup of the same GPU.
+// Optional bf16 wire format: two bf16 per granule (converted while being stored: no conversion launches), summed in
+// fp32; the reducing rank rounds its own result through bf16 as well, so all ranks still hold identical gradients.
 #include "common.h"
 #include <cstring>
+#include <cstdlib>
 
 #define PAR_MAX_RANKS 8
 #define PAR_THREADS 256
-#define PAR_MAX_CHUNKS 64           // chunks per slice (flag array sizing)
-#define PAR_SPIN_LIMIT (1u << 22)   // polls (~64 cycles of sleep each) before a wait gives up: a few seconds
+#define PAR_MAX_CHUNKS 64           // chunks per slice
+#define PAR_SPIN_LIMIT (1u << 21)   // polls (~0.5 us each) before a wait gives up: about a second
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct PeerRegionHeader {           // at the start of every rank's region
-    unsigned flag1[PAR_MAX_RANKS][PAR_MAX_CHUNKS];                    // [source rank][chunk]
-    unsigned flag2[PAR_MAX_RANKS][PAR_MAX_CHUNKS][PAR_MAX_RANKS];     // [source rank][chunk][sub-chunk]
-    unsigned epoch;                 // calls completed by this rank
+    unsigned epoch;                 // calls completed by this rank (+ the region's epoch base)
     unsigned done;                  // workgroups of the current call that have finished
     unsigned error;                 // != 0: a wait timed out (code = phase << 8 | awaited rank)
     unsigned pad[13];
@@ -44,21 +50,20 @@ struct PeerRegionHeader {           // at the start of every rank's region
 
 struct PeerArArgs {
     char* region[PAR_MAX_RANKS];    // every rank's region as mapped in THIS process (own rank: the local pointer)
-    float* local;                   // this rank's gradient (ordinary device memory)
+    float* local;                   // this rank's gradient (ordinary device memory, 16-byte aligned)
     long n;                         // elements
     long slice;                     // elements per rank slice (multiple of 8)
     long chunk;                     // elements per chunk (multiple of 8 * world)
+    long region_bytes;
     int rank, world, chunks;        // chunks per slice (<= PAR_MAX_CHUNKS)
-    int wire_bf16;
 };
 
 namespace {
 
-__host__ __device__ inline long par_stage_off() { return (long)sizeof(PeerRegionHeader); }
-// staging slot s (what rank s sent us) and the result area follow the header; both in wire elements
-__host__ __device__ inline long par_region_bytes(long slice, int world, int wire_bytes) {
-    return par_stage_off() + (long)world * slice * wire_bytes          // staging [world][slice]
-           + (long)world * slice * wire_bytes;                         // result  [world][slice]
+// bytes of one slot (a slice's granules): 8 bytes per fp32 element, 8 bytes per two bf16 elements
+__host__ __device__ inline long par_slot_bytes(long slice, bool bf16) { return slice * (bf16 ? 4 : 8); }
+__host__ __device__ inline long par_region_bytes(long slice, int world, bool bf16) {
+    return (long)sizeof(PeerRegionHeader) + 2L * world * par_slot_bytes(slice, bf16);    // staging + result slots
 }
 
 __device__ __forceinline__ unsigned ld_sys(const unsigned* p) {
@@ -66,32 +71,6 @@ __device__ __forceinline__ unsigned ld_sys(const unsigned* p) {
 }
 __device__ __forceinline__ void st_sys(unsigned* p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// thread 0 waits until *flag has reached `epoch` (flags only grow; the comparison is wrap-safe), everybody follows
-__device__ __forceinline__ bool wait_flag(const unsigned* flag, unsigned epoch, unsigned* err, unsigned code) {
-    __shared__ int ok_s;
-    if (threadIdx.x == 0) {
-        int ok = 1;
-        unsigned spins = 0;
-        while ((int)(ld_sys(flag) - epoch) < 0) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > PAR_SPIN_LIMIT) { ok = 0; atomicExch(err, code); break; }
-        }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);       // system scope: later loads see the data behind the flag
-        ok_s = ok;
-    }
-    __syncthreads();
-    const bool ok = ok_s != 0;
-    __syncthreads();        // ok_s may be rewritten by the next wait
-    return ok;
-}
-
-// every thread's stores are done and visible system-wide, then thread 0 raises the flag
-__device__ __forceinline__ void raise_flag(unsigned* flag, unsigned epoch) {
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) st_sys(flag, epoch);
 }
 
 // 4 gradient elements from ordinary device memory (16-byte aligned base); elements past n read as zero
@@ -104,100 +83,159 @@ __device__ __forceinline__ void load4(const float* base, long e, long n, float* 
         for (int k = 0; k < 4; ++k) f[k] = (e + k < n) ? base[e + k] : 0.f;
     }
 }
+__device__ __forceinline__ void store4(float* base, long e, long n, const float* f) {
+    if (e + 3 < n) {
+        *reinterpret_cast<float4*>(base + e) = make_float4(f[0], f[1], f[2], f[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (e + k < n) base[e + k] = f[k];
+    }
+}
 
+// One 16-byte system-scope access = two granules {payload, tag, payload, tag}.  aux 17 = sc0 | sc1.
+__device__ __forceinline__ void st_pair(__amdgpu_buffer_rsrc_t rsrc, unsigned off, unsigned p0, unsigned p1,
+                                        unsigned tag) {
+    u32x4 v = {p0, tag, p1, tag};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 17);
+}
+__device__ __forceinline__ u32x4 ld_pair(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 17);
+}
+__device__ __forceinline__ bool pair_ok(u32x4 v, unsigned tag) { return v.y == tag && v.w == tag; }
+
+// the wire format: 4 consecutive elements <-> NP granule pairs
 template <bool BF16> struct Wire;
-template <> struct Wire<false> {
-    typedef float4 V;                       // 4 elements per access
-    static constexpr int N = 4;
-    __device__ static V pack(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
-    __device__ static void unpack(V v, float* f) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+template <> struct Wire<false> {        // one fp32 per granule: 4 elements = 2 pairs = 32 bytes
+    static constexpr int NP = 2;
+    static constexpr int BYTES4 = 32;
+    __device__ static void store(__amdgpu_buffer_rsrc_t r, unsigned off, const float* f, unsigned tag) {
+        st_pair(r, off, __float_as_uint(f[0]), __float_as_uint(f[1]), tag);
+        st_pair(r, off + 16, __float_as_uint(f[2]), __float_as_uint(f[3]), tag);
+    }
+    __device__ static void unpack(const u32x4* v, float* f) {
+        f[0] = __uint_as_float(v[0].x); f[1] = __uint_as_float(v[0].z);
+        f[2] = __uint_as_float(v[1].x); f[3] = __uint_as_float(v[1].z);
+    }
+    __device__ static void round_trip(float*) {}
 };
-template <> struct Wire<true> {
-    typedef uint2 V;                        // 4 bf16
-    static constexpr int N = 4;
-    __device__ static V pack(const float* f) { return make_uint2(pack2bf(f[0], f[1]), pack2bf(f[2], f[3])); }
-    __device__ static void unpack(V v, float* f) {
-        f[0] = bf2f((bf16_t)(v.x & 0xffffu)); f[1] = bf2f((bf16_t)(v.x >> 16));
-        f[2] = bf2f((bf16_t)(v.y & 0xffffu)); f[3] = bf2f((bf16_t)(v.y >> 16));
+template <> struct Wire<true> {         // two bf16 per granule: 4 elements = 1 pair = 16 bytes
+    static constexpr int NP = 1;
+    static constexpr int BYTES4 = 16;
+    __device__ static void store(__amdgpu_buffer_rsrc_t r, unsigned off, const float* f, unsigned tag) {
+        st_pair(r, off, pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), tag);
+    }
+    __device__ static void unpack(const u32x4* v, float* f) {
+        f[0] = bf2f((bf16_t)(v[0].x & 0xffffu)); f[1] = bf2f((bf16_t)(v[0].x >> 16));
+        f[2] = bf2f((bf16_t)(v[0].z & 0xffffu)); f[3] = bf2f((bf16_t)(v[0].z >> 16));
+    }
+    __device__ static void round_trip(float* f) {       // what a peer receives of these four values
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f[k] = bf2f(f2bf(f[k]));
     }
 };
 
 template <bool BF16>
 __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs a) {
     typedef Wire<BF16> W;
-    typedef typename W::V V;
     const int p = blockIdx.x / a.chunks, j = blockIdx.x % a.chunks;       // (peer, chunk of that peer's slice)
     const int r = a.rank, world = a.world;
     PeerRegionHeader* me = reinterpret_cast<PeerRegionHeader*>(a.region[r]);
     const unsigned epoch = ld_sys(&me->epoch) + 1u;         // every workgroup reads it before any can finish the call
     const long slice = a.slice, chunk = a.chunk;
     const long c0 = (long)j * chunk, c1 = min(c0 + chunk, slice);          // chunk range within a slice
-    auto stage_of = [&](int owner, int slot) {      // staging slot `slot` in rank `owner`'s region
-        return reinterpret_cast<V*>(a.region[owner] + par_stage_off()) + ((long)slot * slice) / W::N;
+    const unsigned slot = (unsigned)par_slot_bytes(slice, BF16);
+    const unsigned hdr = (unsigned)sizeof(PeerRegionHeader);
+    // region of rank `owner`: staging slot s at hdr + s * slot, result slot s at hdr + (world + s) * slot
+    auto rsrc_of = [&](int owner) {
+        return __builtin_amdgcn_make_buffer_rsrc(a.region[owner], 0, (int)a.region_bytes, 0x00020000);
     };
-    auto result_of = [&](int owner, int sl) {       // reduced slice `sl` in rank `owner`'s result area
-        return reinterpret_cast<V*>(a.region[owner] + par_stage_off()) + ((long)(world + sl) * slice) / W::N;
-    };
-    bool ok = true;
+    const __amdgpu_buffer_rsrc_t mine = rsrc_of(r);
 
     // ---- phase 1: my copy of peer p's slice -> p's staging slot r ----------------------------------------------
     if (p != r) {
-        V* dst = stage_of(p, r);
-        for (long e = c0 + (long)threadIdx.x * W::N; e < c1; e += (long)PAR_THREADS * W::N) {
+        const __amdgpu_buffer_rsrc_t dst = rsrc_of(p);
+        const unsigned base = hdr + (unsigned)r * slot;
+        for (long e = c0 + (long)threadIdx.x * 4; e < c1; e += (long)PAR_THREADS * 4) {
             float f[4];
             load4(a.local, (long)p * slice + e, a.n, f);
-            dst[e / W::N] = W::pack(f);
+            W::store(dst, base + (unsigned)(e / 4) * W::BYTES4, f, epoch);
         }
-        raise_flag(&reinterpret_cast<PeerRegionHeader*>(a.region[p])->flag1[r][j], epoch);
     }
 
-    // ---- phase 2: reduce sub-chunk p of chunk j of MY slice, store it everywhere -----------------------------
+    // ---- phase 2: reduce sub-chunk p of chunk j of MY slice; into my gradient and every peer's result slot r ----
     {
-        const long sub = (chunk / world + W::N - 1) / W::N * W::N;
+        const long sub = chunk / world;                     // multiple of 8 (pda_peer_plan)
         const long s0 = min(c0 + (long)p * sub, c1), s1 = (p == world - 1) ? c1 : min(s0 + sub, c1);
-        for (int s = 0; s < world && ok; ++s)
-            if (s != r) ok = wait_flag(&me->flag1[s][j], epoch, &me->error, (1u << 8) | (unsigned)s);
-        if (ok) {
-            for (long e = s0 + (long)threadIdx.x * W::N; e < s1; e += (long)PAR_THREADS * W::N) {
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int s = 0; s < world; ++s) {           // rank order: the same sum on every run
+        for (long e = s0 + (long)threadIdx.x * 4; e < s1; e += (long)PAR_THREADS * 4) {
+            const unsigned goff = (unsigned)(e / 4) * W::BYTES4;
+            // all peers' granules in flight together, then re-poll whatever has not arrived
+            u32x4 v[PAR_MAX_RANKS][W::NP];
+#pragma unroll
+            for (int s = 0; s < PAR_MAX_RANKS; ++s)
+                if (s < world && s != r) {
+#pragma unroll
+                    for (int h = 0; h < W::NP; ++h) v[s][h] = ld_pair(mine, hdr + (unsigned)s * slot + goff + 16 * h);
+                }
+            for (unsigned spins = 0;;) {
+                bool all_ok = true;
+#pragma unroll
+                for (int s = 0; s < PAR_MAX_RANKS; ++s)
+                    if (s < world && s != r) {
+#pragma unroll
+                        for (int h = 0; h < W::NP; ++h)
+                            if (!pair_ok(v[s][h], epoch)) {
+                                all_ok = false;
+                                v[s][h] = ld_pair(mine, hdr + (unsigned)s * slot + goff + 16 * h);
+                            }
+                    }
+                if (all_ok) break;
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > PAR_SPIN_LIMIT) { atomicExch(&me->error, (1u << 8) | 0xffu); break; }
+            }
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < PAR_MAX_RANKS; ++s)             // rank order: the same sum on every run and rank
+                if (s < world) {
                     float f[4];
                     if (s == r) {
                         load4(a.local, (long)r * slice + e, a.n, f);
-                        if (BF16) { V t = W::pack(f); W::unpack(t, f); }       // what the peers would have received
+                        W::round_trip(f);
                     } else {
-                        W::unpack(stage_of(r, s)[e / W::N], f);
+                        W::unpack(v[s], f);
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) acc[k] += f[k];
                 }
-                const V v = W::pack(acc);
-                for (int q = 0; q < world; ++q) result_of(q, r)[e / W::N] = v;
-            }
+            W::round_trip(acc);                                 // every rank ends up with the same bits
+            store4(a.local, (long)r * slice + e, a.n, acc);
+#pragma unroll
+            for (int q = 0; q < PAR_MAX_RANKS; ++q)
+                if (q < world && q != r)
+                    W::store(rsrc_of(q), hdr + (unsigned)(world + r) * slot + goff, acc, epoch);
         }
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0 && ok)
-            for (int q = 0; q < world; ++q)
-                st_sys(&reinterpret_cast<PeerRegionHeader*>(a.region[q])->flag2[r][j][p], epoch);
     }
 
-    // ---- phase 3: reduced chunk j of slice p -> my gradient buffer ---------------------------------------------
-    for (int sb = 0; sb < world && ok; ++sb)
-        ok = wait_flag(&me->flag2[p][j][sb], epoch, &me->error, (2u << 8) | (unsigned)p);
-    if (ok) {
-        const V* src = result_of(r, p);
-        float* dst = a.local + (long)p * slice;
-        for (long e = c0 + (long)threadIdx.x * W::N; e < c1; e += (long)PAR_THREADS * W::N) {
-            float f[4];
-            W::unpack(src[e / W::N], f);
-            if ((long)p * slice + e + 3 < a.n) {
-                *reinterpret_cast<float4*>(dst + e) = make_float4(f[0], f[1], f[2], f[3]);
-            } else {
+    // ---- phase 3: reduced chunk j of peer p's slice -> my gradient buffer ----------------------------------------
+    if (p != r) {
+        const unsigned base = hdr + (unsigned)(world + p) * slot;
+        for (long e = c0 + (long)threadIdx.x * 4; e < c1; e += (long)PAR_THREADS * 4) {
+            const unsigned goff = base + (unsigned)(e / 4) * W::BYTES4;
+            u32x4 v[W::NP];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if ((long)p * slice + e + k < a.n) dst[e + k] = f[k];
+            for (int h = 0; h < W::NP; ++h) v[h] = ld_pair(mine, goff + 16 * h);
+            for (unsigned spins = 0;;) {
+                bool all_ok = true;
+#pragma unroll
+                for (int h = 0; h < W::NP; ++h)
+                    if (!pair_ok(v[h], epoch)) { all_ok = false; v[h] = ld_pair(mine, goff + 16 * h); }
+                if (all_ok) break;
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > PAR_SPIN_LIMIT) { atomicExch(&me->error, (2u << 8) | (unsigned)p); break; }
             }
+            float f[4];
+            W::unpack(v, f);
+            store4(a.local, (long)p * slice + e, a.n, f);
         }
     }
 
@@ -223,7 +261,7 @@ PDA_EXPORT void pda_peer_plan(long n, int world, long* slice, long* chunk, int* 
     int target = 224 / world;                       // ~224 resident workgroups in all
     if (target > PAR_MAX_CHUNKS) target = PAR_MAX_CHUNKS;
     if (target < 1) target = 1;
-    const long gran = 8L * world;                   // sub-chunks stay 16-byte aligned
+    const long gran = 8L * world;                   // sub-chunks stay whole 16-byte accesses
     long ch = (sl + target - 1) / target;
     ch = (ch + gran - 1) / gran * gran;
     if (ch < gran) ch = gran;
@@ -234,14 +272,19 @@ PDA_EXPORT void pda_peer_plan(long n, int world, long* slice, long* chunk, int* 
 PDA_EXPORT long pda_peer_region_bytes(long n, int world, int wire_bf16) {
     long slice, chunk; int chunks;
     pda_peer_plan(n, world, &slice, &chunk, &chunks);
-    return par_region_bytes(slice, world, wire_bf16 ? 2 : 4);
+    return par_region_bytes(slice, world, wire_bf16 != 0);
 }
 
-// uncached device memory + its IPC handle (64 bytes).  Returns 0 on success, a hipError_t otherwise.
-PDA_EXPORT int pda_peer_alloc(long bytes, void** ptr, void* handle64) {
+// Uncached device memory, zero-filled, + its IPC handle (64 bytes).  Returns 0 on success, a hipError_t otherwise.
+// epoch_base: the region's first call uses tag epoch_base + 1.  Every region a process creates gets a base far above
+// the epochs of all regions before it (the caller counts regions; all ranks create them in the same order), so a
+// granule left over from an EARLIER region at the same address can never look valid to this one.
+PDA_EXPORT int pda_peer_alloc(long bytes, unsigned epoch_base, void** ptr, void* handle64) {
     hipError_t e = hipExtMallocWithFlags(ptr, (size_t)bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) return (int)e;
     e = hipMemset(*ptr, 0, (size_t)bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpy((char*)*ptr + offsetof(PeerRegionHeader, epoch), &epoch_base, sizeof(unsigned), hipMemcpyHostToDevice);
     if (e != hipSuccess) return (int)e;
     e = hipDeviceSynchronize();
     if (e != hipSuccess) return (int)e;
@@ -275,8 +318,10 @@ PDA_EXPORT int pda_peer_allreduce(void* const* regions, void* local, long n, int
     if (world < 2 || world > PAR_MAX_RANKS) return -1;
     PeerArArgs a;
     for (int i = 0; i < PAR_MAX_RANKS; ++i) a.region[i] = i < world ? (char*)regions[i] : nullptr;
-    a.local = (float*)local; a.n = n; a.rank = rank; a.world = world; a.wire_bf16 = wire_bf16;
+    a.local = (float*)local; a.n = n; a.rank = rank; a.world = world;
     pda_peer_plan(n, world, &a.slice, &a.chunk, &a.chunks);
+    a.region_bytes = par_region_bytes(a.slice, world, wire_bf16 != 0);
+    if (a.region_bytes >= (1L << 31)) return -2;            // buffer descriptors address 2 GB
     dim3 grid(world * a.chunks), block(PAR_THREADS);
     if (wire_bf16) hipLaunchKernelGGL(peer_allreduce_kernel<true>, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(peer_allreduce_kernel<false>, grid, block, 0, stream, a);

@@ -78,7 +78,10 @@ __global__ __launch_bounds__(256) void segtree_sample_kernel(const float* __rest
     if (lane == 0) {
         float p = sum[node];
         out_idx[wave] = node;
-        out_w[wave] = __powf(pmin / fmaxf(p, 1e-30f), beta);
+        // (min tree of an empty / partly filled tree holds +inf in its unused leaves: a tree with no positive
+        // leaf at all gives weight 1 instead of inf^beta)
+        const float ratio = (pmin < 3.0e38f && p > 0.f) ? pmin / p : 1.f;
+        out_w[wave] = __powf(ratio, beta);
     }
 }
 PDA_EXPORT void pda_segtree_sample(const void* sum, const void* mn, const int* offs, int depth, int num_leaves,

@@ -14,10 +14,16 @@ LIB_PATH = os.path.join(_HERE, "libpda_host.so")
 _LIB = None
 
 
+LAST_REPORT = {}       # "shm_ring.cpp" -> "compiled" | "reused" for the most recent build()
+
+
 def build(force=False, sanitize=None):
     out = LIB_PATH if sanitize is None else LIB_PATH.replace(".so", "_%s.so" % sanitize)
+    force = force or os.environ.get("PDA_BUILD_FORCE", "0") == "1"
     if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(f) for f in [SRC] + HEADERS):
+        LAST_REPORT.setdefault(os.path.basename(SRC), "reused")    # (lib() re-checks after an explicit build)
         return out
+    LAST_REPORT[os.path.basename(SRC)] = "compiled"
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-o", out + ".tmp%d" % os.getpid(), SRC]
     if sanitize:
         cmd[1:1] = ["-fsanitize=%s" % sanitize, "-g"]

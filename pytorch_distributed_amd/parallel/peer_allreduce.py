@@ -40,7 +40,7 @@ def _lib():
         L.pda_peer_plan.restype = None
         L.pda_peer_region_bytes.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int]
         L.pda_peer_region_bytes.restype = ctypes.c_long
-        L.pda_peer_alloc.argtypes = [ctypes.c_long, ctypes.POINTER(_vp), ctypes.c_char_p]
+        L.pda_peer_alloc.argtypes = [ctypes.c_long, ctypes.c_uint, ctypes.POINTER(_vp), ctypes.c_char_p]
         L.pda_peer_alloc.restype = ctypes.c_int
         L.pda_peer_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(_vp)]
         L.pda_peer_open.restype = ctypes.c_int
@@ -65,6 +65,9 @@ def plan(numel, world):
     return sl.value, ch.value, n.value
 
 
+_regions_created = 0        # per process; every rank creates its regions in the same (collective) order
+
+
 class PeerAllReduce(object):
     """In-place SUM all-reduce of ONE fixed fp32 device buffer of `numel` elements over the ranks of `comm`
     (a TorchComm: used only to exchange the 64-byte IPC handles).  wire="bf16" sends slices as bf16."""
@@ -82,15 +85,20 @@ class PeerAllReduce(object):
         torch.cuda.set_device(self.device)
         nbytes = L.pda_peer_region_bytes(self.numel, self.world, self.wire_bf16)
         ptr, handle = _vp(), ctypes.create_string_buffer(64)
-        rc = L.pda_peer_alloc(nbytes, ctypes.byref(ptr), handle)
+        global _regions_created
+        _regions_created += 1
+        self.epoch_base = (_regions_created << 22) & 0x7FFFFFFF       # 4 M calls per region before bases could meet
+        rc = L.pda_peer_alloc(nbytes, self.epoch_base, ctypes.byref(ptr), handle)
         mine = {"rank": self.rank, "rc": int(rc), "handle": handle.raw if rc == 0 else b"", "pid": os.getpid(),
-                "bytes": int(nbytes)}
+                "bytes": int(nbytes), "epoch_base": self.epoch_base}
         if rc == 0:
             self.local = ptr.value
         everyone = [None] * self.world
         dist.all_gather_object(everyone, mine, group=getattr(comm, "group", None))
         err = None
-        if any(e["rc"] != 0 for e in everyone):
+        if len({e["epoch_base"] for e in everyone}) != 1:
+            err = "ranks disagree on the region's epoch base (regions must be created in the same order everywhere)"
+        elif any(e["rc"] != 0 for e in everyone):
             err = "hipExtMallocWithFlags / hipIpcGetMemHandle failed on ranks %s" % [e["rank"] for e in everyone if e["rc"]]
         regions = [0] * self.world
         if err is None:
@@ -229,12 +237,22 @@ def _worker():
         peer = PeerAllReduce(comm, numel, dev, wire=wire)
         g = torch.Generator(device=dev).manual_seed(1234 + 17 * rank)
         x = torch.randn(numel, device=dev, generator=g)
-        ref = x.clone()
-        comm.all_reduce_sum_(ref)                    # the process group's own sum
+        # reference: every rank's vector gathered on the host and added in rank order -- the order the kernel uses,
+        # so the fp32 wire result must match it bit for bit
+        mine = x.cpu()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=comm.group)
+        ref = parts[0].clone()
+        for part in parts[1:]:
+            ref += part
+        ref = ref.to(dev)
+        guard_lo = torch.full((4096,), 7.0, device=dev)
         got = x.clone()
+        guard_hi = torch.full((4096,), 7.0, device=dev)
         peer.all_reduce_sum_(got)
         torch.cuda.synchronize(dev)
-        tol = (1e-6 if wire == "fp32" else 2e-2) * float(ref.abs().max().item())
+        untouched = bool(torch.equal(x.cpu(), mine) and (guard_lo == 7.0).all() and (guard_hi == 7.0).all())
+        tol = 0.0 if wire == "fp32" else 2e-2 * float(ref.abs().max().item())
         err = float((got - ref).abs().max().item())
         # every rank must hold the SAME bits: compare with rank 0's result
         r0 = got.clone()
@@ -267,7 +285,13 @@ def _worker():
         case = {"numel": numel, "wire": wire, "max_err_vs_group_sum": err, "tol": tol, "same_bits_on_all_ranks": same,
                 "chained_calls_ok": chained, "graph_replay_ok": graphed, "us_per_call_in_graph": round(1e6 * dt, 1),
                 "kernel_error_word": peer.error(), "plan": plan(numel, world)}
-        good = err <= tol and same and chained and graphed and case["kernel_error_word"] == 0
+        if err > tol:       # where, and what the two sums and this rank's own contribution are there
+            bad = ((got - ref).abs() > tol).nonzero().reshape(-1)
+            case["bad_count"] = int(bad.numel())
+            case["bad_first"] = [(int(i), float(got[i]), float(ref[i]), float(x[i])) for i in bad[:6].tolist()]
+            case["bad_last"] = [(int(i), float(got[i]), float(ref[i]), float(x[i])) for i in bad[-3:].tolist()]
+        case["inputs_and_neighbours_untouched"] = untouched
+        good = err <= tol and same and chained and graphed and untouched and case["kernel_error_word"] == 0
         ok_all = ok_all and comm.all_agree(good)
         out["cases"].append(case)
         peer.close()

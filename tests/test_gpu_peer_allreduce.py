@@ -1,8 +1,8 @@
 """The xGMI peer all-reduce (ops/csrc/peer_allreduce.hip) across PROCESSES: N ranks map each other's uncached
 hand-off regions through hipIpc handles and reduce with one kernel per call.  The build pool has one GPU per
 box, so all ranks share cuda:0 here -- the peer regions are IPC mappings exactly as they are across GPUs; what
-the one-GPU rehearsal cannot show is the link bandwidth.  Checked per rank: the sum equals the process group's
-(gloo) sum, every rank holds the same bits, back-to-back calls and hipGraph replays keep working (the epoch is
+the one-GPU rehearsal cannot show is the link bandwidth.  Checked per rank: the sum equals -- bit for bit on the fp32
+wire -- the rank-ordered sum of all ranks' vectors gathered on the host, every rank holds the same bits, back-to-back calls and hipGraph replays keep working (the epoch is
 handed over in device memory), and no wait timed out.
 
 Replaces the reference's abandoned gradient hand-off (/root/reference/utils/helpers.py:28-34)."""
@@ -46,7 +46,19 @@ def _launch(world, timeout=110):
 def test_peer_allreduce_across_processes(world):
     outs = _launch(world)
     for rc, out, err in outs:
-        assert rc == 0, (out[-1500:], err[-1500:])
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        assert lines, (rc, out[-800:], err[-1500:])
+        res = json.loads(lines[-1])
+        bad = [{k: c.get(k) for k in ("numel", "wire", "max_err_vs_group_sum", "tol", "same_bits_on_all_ranks",
+                                      "chained_calls_ok", "graph_replay_ok", "kernel_error_word", "bad_count",
+                                      "inputs_and_neighbours_untouched",
+                                      "bad_first", "bad_last", "plan")}
+               for c in res["cases"] if not (c["max_err_vs_group_sum"] <= c["tol"] and c["same_bits_on_all_ranks"]
+                                             and c["inputs_and_neighbours_untouched"]
+                                             and c["chained_calls_ok"] and c["graph_replay_ok"]
+                                             and c["kernel_error_word"] == 0)]
+        assert not bad, "rank %d: %s" % (res["rank"], bad)
+        assert rc == 0, (out[-800:], err[-800:])
     for rc, out, err in outs:
         res = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
         assert res["ok"] and res["world"] == world
