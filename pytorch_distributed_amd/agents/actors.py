@@ -12,6 +12,7 @@ Two ways to pick actions:
   epilogue.
 """
 import os
+import time
 
 import numpy as np
 import torch
@@ -36,6 +37,10 @@ def _maybe_fault(args, role, process_ind, step):
     try:
         who, when = spec.split("@")
         r, idx = who.split(":")
+        if r == "hang-" + role and int(idx) == process_ind and step == int(when):
+            import time
+            while True:                 # alive but silent: what the supervisor's watchdog is for
+                time.sleep(1.0)
         if r == role and int(idx) == process_ind and step == int(when):
             marker = os.path.join(args.log_dir, "fault_%s_%d.done" % (role, process_ind))
             if not os.path.exists(marker):      # only the first incarnation dies
@@ -151,6 +156,8 @@ def _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model
     pending = None
     if mailbox is not None:     # every env has one request in flight; the server batches across actors
         pending = [mailbox.send(w.slot, w.begin()) for w in workers]
+    global_logs.beat("actor", process_ind)
+    last_beat = time.time()
     while global_logs.running(ap.steps):
         for j, w in enumerate(workers):
             if mailbox is not None:
@@ -161,8 +168,9 @@ def _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model
             if mailbox is not None:
                 pending[j] = mailbox.send(w.slot, w.begin())    # in flight while the other envs are stepped
 
-            with global_logs.actor_step.get_lock():
-                global_logs.actor_step.value += 1
+            # (the reference locks one shared mp.Value here for every env step of every actor,
+            # dqn_actor.py:166-167; each process adds to its own cache line instead)
+            global_logs.actor_step.add(process_ind)
             step += 1
             if local_model is not None and step % ap.actor_sync_freq == 0:
                 sync_params(local_model, global_model)
@@ -176,8 +184,11 @@ def _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model
                     actor_logs.total_reward.value += tot[1]
                     actor_logs.nepisodes.value += tot[2]
                     actor_logs.nepisodes_solved.value += tot[3]
-                global_logs.beat("actor")
             _maybe_fault(args, "actor", process_ind, step)
+        now = time.time()
+        if now - last_beat > 1.0:       # sign of life for the supervisor's watchdog (launcher.py)
+            global_logs.beat("actor", process_ind)
+            last_beat = now
 
 
 def dqn_actor(process_ind, args, global_logs, actor_logs, env_prototype, model_prototype,

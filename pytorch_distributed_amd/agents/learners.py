@@ -59,9 +59,13 @@ class _TorchCore(object):
             return (weights * (pred - target) ** 2).mean()
         return self.ap.value_criteria(pred, target)
 
-    def _finish(self, td_abs, inds):
+    def _finish(self, td_abs, inds, clip_params=()):
+        """All-reduce, THEN clip: every back-end clips the rank-averaged gradient (= the gradient of the large
+        batch), so the torch oracle and the native engine agree in data-parallel runs with a finite clip."""
         if self.comm.world_size > 1:
             self.comm.all_reduce_mean_(self.model.flat_grads)
+        for params in clip_params:
+            _clip_value_(params, self.ap.clip_grad)
         self.optimizer.step()
         update_target_model(self.model, self.target_model, self.ap.target_model_update, self.step_count)
         if self.memory.enable_per:
@@ -116,9 +120,8 @@ class DqnTorchCore(_TorchCore):
         pred = self.model(s0).gather(1, a.long())
         loss = self._weighted_mse(pred, target, w)
         loss.backward()
-        _clip_value_(self.model.critic.parameters(), self.ap.clip_grad)
         self.last_losses = {"critic_loss": loss.detach()}
-        self._finish((pred.detach() - target).abs(), inds)
+        self._finish((pred.detach() - target).abs(), inds, clip_params=[list(self.model.critic.parameters())])
 
 
 class DdpgTorchCore(_TorchCore):
@@ -139,16 +142,18 @@ class DdpgTorchCore(_TorchCore):
         if not leak:
             for p in self.model.critic.parameters():
                 p.requires_grad_(True)
-        _clip_value_(self.model.actor.parameters(), self.ap.clip_grad)
+        # (single rank: the reference clips the actor's gradients here, before the critic loss adds to the critic's
+        # (ddpg_learner.py:74); clipping is elementwise and the two parameter sets are disjoint, so clipping both
+        # after the critic backward -- and, with several ranks, after the all-reduce -- is the same arithmetic)
         with torch.no_grad():
             _, next_q = self.target_model(s1)
             target = r + g * next_q * (1 - t)
         pred = self.model.forward_critic(s0, a)
         critic_loss = self._weighted_mse(pred, target, w)
         critic_loss.backward()
-        _clip_value_(self.model.critic.parameters(), self.ap.clip_grad)
         self.last_losses = {"actor_loss": actor_loss.detach(), "critic_loss": critic_loss.detach()}
-        self._finish((pred.detach() - target).abs(), inds)
+        self._finish((pred.detach() - target).abs(), inds, clip_params=[list(self.model.actor.parameters()),
+                                                                         list(self.model.critic.parameters())])
 
 
 def _pick_compute(args, device):
@@ -225,10 +230,18 @@ def load_learner_resume(args, core):
     if (d.get("kind") == "native") != native:
         print("[learner] resume file %s was written by the %s step back-end; only weights are restored"
               % (path, d.get("kind")))
+        print("[learner] ... and the target network; the optimizer moments restart from zero")
         with torch.no_grad():
             core.flat_params().copy_(d["params"])
+            if native:
+                core.engine.target.flat.copy_(d["target"])
+            else:
+                core.target_model.flat_params.copy_(d["target"])
         if native:
             core.engine.online.refresh()
+            core.engine.target.refresh()
+            core.engine.step_count = int(d.get("step_count", d["learner_step"]))
+        core.step_count = int(d.get("step_count", d["learner_step"]))
         return int(d["learner_step"]), int(d["actor_step"])
     if native:
         native_load_resume_state(core, d)
@@ -294,14 +307,9 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
 
     # weight hand-off (rank 0): seqlocked host buffer for evaluator / local actors (asynchronous D2H),
     # plus a collective broadcast to the inference rank when it owns another GPU
-    shm_pub = AsyncParamPublisher(global_model, local_device) if rank == 0 else None
-    bcast_pub = None
-    if rank == 0 and collective_sync:
-        bcast_pub = WeightPublisher(comm, core.flat_params().numel(), local_device)
-        bcast_pub.publish(core.flat_params())
-
     step = 0
-    if getattr(args, "resume", False):
+    restored = None
+    if getattr(args, "resume", False):     # before the first publish: actors / evaluator must never see pre-resume weights
         restored = load_learner_resume(args, core)      # every rank loads the same sidecar
         if restored is not None:
             step = restored[0]
@@ -309,15 +317,38 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
                 global_logs.learner_step.value = restored[0]
                 global_logs.actor_step.value = restored[1]
                 print("[learner] resumed from %s at learner step %d" % (_resume_path(args), step))
+    shm_pub = AsyncParamPublisher(global_model, local_device) if rank == 0 else None
+    if shm_pub is not None and restored is not None:
+        shm_pub.publish(core.flat_params(), force=True)
+    bcast_pub = None
+    if rank == 0 and collective_sync:
+        bcast_pub = WeightPublisher(comm, core.flat_params().numel(), local_device)
+        bcast_pub.publish(core.flat_params())
     resume_freq = int(getattr(args, "resume_freq", 0))
     # the reference has no actor/learner rate coupling: the replay ratio is whatever the
     # two speeds give.  With a learner that is 15x faster that ratio explodes, so it can be capped:
     # at most `max_replay_ratio` learner updates per env step taken by the actors (0 = unlimited)
     max_ratio = float(getattr(ap, "max_replay_ratio", 0.0) or 0.0)
     started = False
-    while step < ap.steps and not global_logs.stop.value:
+    # Leaving the loop is a COLLECTIVE decision when there are several ranks: a rank that saw `stop` and left while
+    # its peers entered the next step's all-reduce would leave them blocked in it.  Every `agree_every` steps (and on
+    # every pass while waiting for data) the ranks MIN-reduce "keep going"; in between nobody looks at the flag.
+    agree_every = max(1, int(getattr(args, "stop_agree_every", 64)))
+    global_logs.beat("learner", process_ind)
+    last_beat = time.time()
+    from .actors import _maybe_fault
+    while step < ap.steps:
+        now = time.time()
+        if now - last_beat > 1.0:           # sign of life for the supervisor's watchdog (launcher.py)
+            global_logs.beat("learner", process_ind)
+            last_beat = now
+        if world > 1:
+            if (not started or step % agree_every == 0) and not comm.all_agree(not global_logs.stop.value):
+                break
+        elif global_logs.stop.value:
+            break
         if hasattr(global_memory, "drain"):
-            global_logs.frames_ingested.value += global_memory.drain()
+            global_logs.frames_ingested.add(rank, global_memory.drain())
         if not started:
             ready = global_memory.size > ap.learn_start
             started = comm.all_agree(ready)
@@ -331,6 +362,7 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
                 continue
         core.step()
         step += 1
+        _maybe_fault(args, "learner", rank, step)
         if rank == 0:
             with global_logs.learner_step.get_lock():
                 global_logs.learner_step.value += 1
@@ -343,7 +375,6 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
                 for name, val in core.loss_values().items():
                     getattr(learner_logs, name).value += val
                 learner_logs.loss_counter.value += 1
-                global_logs.beat("learner")
     if rank == 0:
         if getattr(args, "save_resume", True):
             save_learner_resume(args, core, step, global_logs.actor_step.value)

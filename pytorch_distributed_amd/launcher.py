@@ -54,51 +54,121 @@ def build_global_model(opt):
 
 
 class Supervisor(object):
-    """Keeps the process table; restarts actors, stops the job on learner death."""
+    """Keeps the process table.  The reference just join()s (main.py:117-118): a crashed actor goes unnoticed and a
+    crashed learner leaves every other process spinning on `learner_step < steps` forever.  Here:
+
+    * a dead actor is restarted (actors are stateless); a dead learner / inference process raises the shared stop
+      flag and the job ends with that exit code;
+    * heartbeats are CONSUMED: every worker stamps its slot of `global_logs.heartbeats` about once a second; a
+      learner / inference process whose stamp is older than `watchdog_learner_s` is treated as hung (stop flag, then
+      terminated), a stale actor is terminated and restarted;
+    * shutdown is bounded: once the job is over -- steps reached, stop flag, or a fatal exit -- the remaining
+      processes get `shutdown_grace_s` seconds and are then terminated (a learner rank blocked in a collective
+      whose peer died never looks at the stop flag again) and, if need be, killed."""
+
+    FATAL_ROLES = ("learner", "inference")
 
     def __init__(self, opt, global_logs, ctx):
         self.opt, self.global_logs, self.ctx = opt, global_logs, ctx
-        self.procs = []     # (role, index, spec, Process)
+        self.procs = []     # [role, index, (target, args), Process]
         self.restarts = 0
+        self.hung = []      # (role, index) of processes the watchdog gave up on
+        self.failed = None  # (role, index, exitcode | "hung") of the first fatal failure
+        self.started_at = {}
+        self.watchdog_learner_s = float(getattr(opt, "watchdog_learner_s", 120.0))
+        self.watchdog_actor_s = float(getattr(opt, "watchdog_actor_s", 120.0))
+        self.shutdown_grace_s = float(getattr(opt, "shutdown_grace_s", 20.0))
 
     def start(self, role, index, target, args):
         p = self.ctx.Process(target=target, args=args, name="%s-%d" % (role, index))
         p.start()
+        self.started_at[(role, index)] = time.time()
         self.procs.append([role, index, (target, args), p])
         return p
+
+    def _restart(self, entry, why):
+        role, index, (target, args), p = entry
+        print("[supervisor] %s %d %s: restarting" % (role, index, why), flush=True)
+        if p.is_alive():
+            p.terminate()
+            p.join(5)
+            if p.is_alive():
+                p.kill()
+        if self.global_logs is not None:
+            self.global_logs.beat(role, index)      # the new incarnation gets a full period to show up
+        np_ = self.ctx.Process(target=target, args=args, name="%s-%d" % (role, index))
+        np_.start()
+        self.started_at[(role, index)] = time.time()
+        entry[3] = np_
+        self.restarts += 1
+
+    def _stale(self, role, index, limit):
+        """True when the process has beaten before (or has had `limit` seconds to start) and its last beat is
+        older than `limit` seconds."""
+        if limit <= 0 or self.global_logs is None:
+            return False
+        last = self.global_logs.last_beat(index)
+        ref = last if last > 0 else self.started_at.get((role, index), time.time())
+        return time.time() - ref > limit
 
     def poll(self):
         """One supervision pass.  Returns False when everything has exited."""
         alive = False
         steps = self.opt.agent_params.steps
+        gl = self.global_logs
         for entry in self.procs:
-            role, index, (target, args), p = entry
+            role, index, _, p = entry
+            running = gl is not None and gl.running(steps)
             if p.is_alive():
                 alive = True
+                if not running or not self.opt.supervise:
+                    continue
+                if role == "actor" and self._stale(role, index, self.watchdog_actor_s):
+                    self._restart(entry, "has not beaten for %.0f s (hung)" % self.watchdog_actor_s)
+                elif role in self.FATAL_ROLES and self._stale(role, index, self.watchdog_learner_s):
+                    print("[supervisor] %s %d has not beaten for %.0f s (hung): stopping the job"
+                          % (role, index, self.watchdog_learner_s), flush=True)
+                    self.hung.append((role, index))
+                    self.failed = self.failed or (role, index, "hung")
+                    gl.stop.value = True
                 continue
-            if p.exitcode not in (0, None) and self.global_logs is not None \
-                    and self.global_logs.running(steps):
+            if p.exitcode not in (0, None) and running:
                 if role == "actor" and self.opt.supervise:
-                    print("[supervisor] actor %d died (exit %s): restarting" % (index, p.exitcode))
-                    np_ = self.ctx.Process(target=target, args=args, name="actor-%d" % index)
-                    np_.start()
-                    entry[3] = np_
-                    self.restarts += 1
+                    self._restart(entry, "died (exit %s)" % p.exitcode)
                     alive = True
-                elif role in ("learner", "inference"):
-                    print("[supervisor] %s %d died (exit %s): stopping the job" % (role, index, p.exitcode))
-                    self.global_logs.stop.value = True
+                elif role in self.FATAL_ROLES:
+                    print("[supervisor] %s %d died (exit %s): stopping the job" % (role, index, p.exitcode), flush=True)
+                    self.failed = self.failed or (role, index, p.exitcode)
+                    gl.stop.value = True
         return alive
 
     def join(self, poll_s=0.5):
+        """Supervise until the job is over, then give what is left a bounded time to leave."""
+        steps = self.opt.agent_params.steps
+        deadline = None
         while self.poll():
+            if deadline is None and self.global_logs is not None and not self.global_logs.running(steps):
+                deadline = time.time() + self.shutdown_grace_s
+            if deadline is not None and time.time() > deadline:
+                break
             time.sleep(poll_s)
-        deadline = time.time() + 30
-        for _, _, _, p in self.procs:
-            p.join(max(0.1, deadline - time.time()))
+        for role, index, _, p in self.procs:
             if p.is_alive():
+                print("[supervisor] %s %d still running %.0f s after the end of the job: terminating"
+                      % (role, index, self.shutdown_grace_s), flush=True)
                 p.terminate()
+        t_end = time.time() + 10
+        for _, _, _, p in self.procs:
+            p.join(max(0.1, t_end - time.time()))
+            if p.is_alive():
+                p.kill()
+                p.join(5)
         return [p.exitcode for _, _, _, p in self.procs]
+
+    @property
+    def ok(self):
+        """The job ran to its end: no fatal failure, no watchdog kill."""
+        return self.failed is None and not self.hung
 
 
 def run(opt):

@@ -212,11 +212,13 @@ def inference_server(process_ind, args, global_logs, model_prototype, global_mod
     try:
         native = _native_server(args, model, mailbox, device)
         if native is not None:
-            _serve_native(args, global_logs, global_model, native, version, receiver=receiver)
+            _serve_native(args, global_logs, global_model, native, version, receiver=receiver,
+                          process_ind=process_ind)
         else:
             policy = BatchedPolicy(args, model, device)
             policy.refresh()
-            _serve(args, global_logs, global_model, mailbox, model, policy, device, version, receiver=receiver)
+            _serve(args, global_logs, global_model, mailbox, model, policy, device, version, receiver=receiver,
+                   process_ind=process_ind)
     finally:
         mailbox.closed[0] = 1
         if receiver is not None:
@@ -225,12 +227,13 @@ def inference_server(process_ind, args, global_logs, model_prototype, global_mod
             comm.close()
 
 
-def _serve_native(args, global_logs, global_model, native, version, poll_s=0.02, receiver=None):
+def _serve_native(args, global_logs, global_model, native, version, poll_s=0.02, receiver=None, process_ind=0):
     """The C++ loop thread answers the actors; this thread only re-syncs the weights."""
     native.start()
     try:
         while global_logs.running(args.agent_params.steps):
             time.sleep(poll_s)
+            global_logs.beat("inference", process_ind)     # watchdog (launcher.Supervisor)
             if receiver is not None:
                 native.refresh_from_receiver(receiver)
                 continue
@@ -246,11 +249,15 @@ def _serve_native(args, global_logs, global_model, native, version, poll_s=0.02,
         native.close()
 
 
-def _serve(args, global_logs, global_model, mailbox, model, policy, device, version, receiver=None):
+def _serve(args, global_logs, global_model, mailbox, model, policy, device, version, receiver=None, process_ind=0):
     eps_dev = None
     served, last_sync = 0, 0
     idle = 0
+    last_beat = 0.0
     while global_logs.running(args.agent_params.steps):
+        if time.time() - last_beat > 1.0:
+            last_beat = time.time()
+            global_logs.beat("inference", process_ind)     # watchdog (launcher.Supervisor)
         ids, req_seen = mailbox.pending()
         if len(ids) == 0:
             idle += 1

@@ -11,3 +11,4 @@ ctx = mp.get_context("spawn")
 Value = ctx.Value
 Lock = ctx.Lock
 Process = ctx.Process
+RawArray = ctx.RawArray

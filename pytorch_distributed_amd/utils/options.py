@@ -142,7 +142,13 @@ class Params(object):
         self.precision = "fp32"
         self.param_sync_freq = 25           # learner publishes weights every this many learner steps
         self.supervise = True               # restart dead actors, stop everything if a learner dies
-        self.inject_fault = None            # e.g. "actor:1@50" kills actor 1 at its 50th step (tests)
+        self.inject_fault = None            # "actor:1@50" kills actor process 1 at its 50th step, "learner:1@20" learner
+                                            # rank 1 after its 20th update, "hang-learner:0@20" makes rank 0 stop
+                                            # beating there (tests of the supervisor)
+        self.watchdog_learner_s = 120.0     # a learner / inference process silent for this long is hung: the job stops
+        self.watchdog_actor_s = 120.0       # a silent actor is terminated and restarted (0: no watchdog)
+        self.shutdown_grace_s = 20.0        # time the remaining processes get once the job is over, before terminate()
+        self.stop_agree_every = 64          # several learner ranks: they agree on leaving the loop every this many steps
         self.ingest = "ring"                # "ring": lock-free shm ring into device replay | "direct"
         self.force_dp = False               # run the data-parallel step program even with one learner (rehearsal)
         self.graph_steps = 5                # native DQN learner, HBM replay, one rank: updates per hipGraph replay (the

@@ -89,10 +89,14 @@ def test_fake_comm_collectives():
     assert all(torch.equal(t, torch.ones(3)) for t in ts)
 
 
-def test_dp_two_ranks_equal_one_rank_with_double_batch():
-    """Synchronous DP: 2 ranks x B/2 with the gradient mean == 1 rank x B (reference has only Hogwild)."""
+@pytest.mark.parametrize("clip", [float("inf"), 0.02])
+def test_dp_two_ranks_equal_one_rank_with_double_batch(clip):
+    """Synchronous DP: 2 ranks x B/2 with the gradient mean == 1 rank x B (reference has only Hogwild) -- also with
+    a finite value clip that bites (0.02): every back-end clips the rank-AVERAGED gradient, i.e. after the
+    all-reduce, so data parallelism stays equivalent to the large batch."""
     B, world, steps = 16, 2, 5
     opt = _mlp_opt(B)
+    opt.agent_params.clip_grad = clip
     D, A = int(np.prod(opt.state_shape)), opt.action_space
     full = _dqn_batches(steps, B, D, A, seed=3)
     torch.manual_seed(0)
@@ -100,12 +104,14 @@ def test_dp_two_ranks_equal_one_rank_with_double_batch():
                                        opt.action_shape)
     single = DqnTorchCore(opt, copy.deepcopy(proto), copy.deepcopy(proto), FixedBatchMemory(full), SingleComm())
     opt_half = _mlp_opt(B // world)
+    opt_half.agent_params.clip_grad = clip
     comms = FakeComm.create(world)
     ranks = []
     for r in range(world):
         shard = [_split(b, world)[r] for b in full]
         ranks.append(DqnTorchCore(opt_half, copy.deepcopy(proto), copy.deepcopy(proto), FixedBatchMemory(shard),
                                   comms[r]))
+    clipped = 0
     # FakeComm finishes a collective when the last rank arrives, so run the ranks' steps in
     # lock-step threads-free fashion: interleave by monkeypatching _finish to defer after all backward passes
     for _ in range(steps):
@@ -113,15 +119,17 @@ def test_dp_two_ranks_equal_one_rank_with_double_batch():
         pending = []
         for core in ranks:
             orig = core._finish
-            core._finish = lambda td, inds, _c=core: pending.append((_c, td, inds))
+            core._finish = lambda td, inds, _c=core, **kw: pending.append((_c, td, inds, kw))
             core.step()
             core._finish = orig
-        for core, td, inds in pending:
+        for core, td, inds, kw in pending:
             core.comm.all_reduce_mean_(core.model.flat_grads)
-        for core, td, inds in pending:
+        clipped += int((ranks[0].model.flat_grads.abs() > clip).sum())
+        for core, td, inds, kw in pending:
             comm, core.comm = core.comm, SingleComm()
-            core._finish(td, inds)
+            core._finish(td, inds, **kw)
             core.comm = comm
+    assert clip == float("inf") or clipped > 0      # the finite clip really bit
     ref = single.model.flat_params
     for core in ranks:
         assert _same_params(core.model.flat_params, ref), (core.model.flat_params - ref).abs().max()
@@ -217,14 +225,14 @@ def test_ddpg_dp_equivalence_fake_comm():
         core = DdpgTorchCore(opt_h, copy.deepcopy(proto), copy.deepcopy(proto),
                              FixedBatchMemory([_split(full[0], world)[r]]), comms[r])
         core._finish_real = core._finish
-        core._finish = lambda td, inds, _c=core: pending.append((_c, td, inds))
+        core._finish = lambda td, inds, _c=core, **kw: pending.append((_c, td, inds, kw))
         core.step()
         cores.append(core)
-    for core, td, inds in pending:
+    for core, td, inds, kw in pending:
         core.comm.all_reduce_mean_(core.model.flat_grads)
-    for core, td, inds in pending:
+    for core, td, inds, kw in pending:
         core.comm = SingleComm()
-        core._finish_real(td, inds)
+        core._finish_real(td, inds, **kw)
     # value-clip happens per rank before the mean in DP, after it on one rank: identical while no
     # gradient element reaches the clip (40), which holds for this data
     for core in cores:

@@ -113,3 +113,60 @@ def test_multi_env_actors_with_batched_inference(tmp_root):
     assert opt.env_params.num_envs_per_actor == 3
     sup = run(opt)
     check_common(opt, sup, 25)
+
+
+# ---- failure handling (the reference's main.py:117-118 only join()s) -----------------------------
+def test_learner_rank_death_tears_the_job_down_in_bounded_time(tmp_root):
+    """Two data-parallel learner ranks over gloo; rank 1 dies after its 5th update.  Rank 0 is then inside (or on
+    its way into) an all-reduce that can never complete and never looks at the stop flag again: the supervisor must
+    notice the death, raise the flag, give the rest a bounded grace period, terminate what is left and report
+    non-zero exit codes -- instead of hanging until the collective's own timeout (600 s)."""
+    import time
+    opt = opts(6, tmp_root, num_learners=2, timestamp="dead", inject_fault="learner:1@5", shutdown_grace_s=4.0,
+               **{"agent_params.steps": 100000, "agent_params.learn_start": 40})
+    t0 = time.time()
+    sup = run(opt)
+    wall = time.time() - t0
+    assert wall < 90, wall
+    assert sup.failed is not None and sup.failed[0] == "learner" and sup.failed[2] == 17
+    assert not sup.ok
+    codes = {(role, index): p.exitcode for role, index, _, p in sup.procs}
+    learners = [c for (role, _), c in codes.items() if role == "learner"]
+    assert 17 in learners and all(c is not None for c in codes.values())      # nobody left running
+    assert any(c != 0 for c in learners)
+
+
+def test_watchdog_stops_the_job_when_the_learner_hangs(tmp_root):
+    """Heartbeats are consumed: a learner that is alive but silent (injected hang) is declared hung after
+    watchdog_learner_s, the job stops and the hung process is terminated."""
+    import time
+    opt = opts(6, tmp_root, timestamp="hang", inject_fault="hang-learner:0@8", watchdog_learner_s=3.0,
+               shutdown_grace_s=3.0, **{"agent_params.steps": 100000, "agent_params.learn_start": 40})
+    t0 = time.time()
+    sup = run(opt)
+    assert time.time() - t0 < 90
+    assert sup.hung and sup.hung[0][0] == "learner" and not sup.ok
+    assert sup.failed == ("learner", sup.hung[0][1], "hung")
+    assert all(p.exitcode is not None for *_, p in sup.procs)
+
+
+def test_watchdog_restarts_a_hung_actor(tmp_root):
+    opt = opts(6, tmp_root, timestamp="hanga", inject_fault="hang-actor:1@15", watchdog_actor_s=3.0,
+               **{"agent_params.steps": 2500, "agent_params.learn_start": 40})
+    sup = run(opt)
+    assert sup.restarts >= 1 and sup.ok
+    assert all(c == 0 for (role, *_), c in zip(sup.procs, sup.exitcodes) if role != "actor"), sup.exitcodes
+
+
+def test_sharded_step_counter_keeps_the_reference_idiom():
+    from pytorch_distributed_amd.agents.logs import GlobalLogs
+    g = GlobalLogs()
+    g.actor_step.add(3)
+    g.actor_step.add(700, 5)
+    with g.actor_step.get_lock():       # dqn_actor.py:166-167 still works
+        g.actor_step.value += 1
+    assert g.actor_step.value == 7
+    g.actor_step.value = 100            # resume
+    assert g.actor_step.value == 100
+    g.beat("actor", 12)
+    assert g.last_beat(12) > 0 and g.last_beat(13) == 0
