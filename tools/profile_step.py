@@ -136,7 +136,8 @@ def main():
         # GEMM (64x64 tiles, 4 waves x 2x2 fragments of 16x16x32): per launch
         #   groups * ceil(B/64) * (512/64) tiles * sum over k-slices of ceil(len/64) k-tiles * 2 k-steps * 16 MFMA per tile
         for k, c in merged.items():
-            if "EpiAtomicF32" in k and "SrcDenseK" in k and "SrcSplit" not in k and a.precision == "bf16":
+            if ("EpiAtomicF32" in k or "EpiSlabF32" in k) and "SrcDenseK" in k and "SrcSplit" not in k \
+                    and a.precision == "bf16":
                 import math
                 B, F, HID, groups = a.batch, 3136, 512, 2
                 tiles = groups * math.ceil(B / 64) * (HID // 64)
