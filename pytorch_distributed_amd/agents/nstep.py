@@ -10,8 +10,6 @@
 * windows never straddle episodes;
 * with PER the initial priority is |R + gamma^k max_a Q(s_k) - Q(s0, a0)| using
   the actor's own (stale) network.
-
-`nstep_batch_returns` is the vectorised form used by the device-side actor pool.
 """
 from collections import deque
 
@@ -74,14 +72,6 @@ class NStepAssembler(object):
         prio = self._priority(ret, gamma_sn, max_qvalue_last, self.qvalues[first])
         return [((self.states[first], self.actions[first], [ret], [gamma_sn],
                   self.states[-1], self.terminals[-1]), prio)]
-
-
-def nstep_batch_returns(rewards, gamma):
-    """rewards (..., k) -> discounted sums (...,) and gamma^k."""
-    rewards = np.asarray(rewards, dtype=np.float64)
-    k = rewards.shape[-1]
-    disc = gamma ** np.arange(k)
-    return (rewards * disc).sum(-1), gamma ** k
 
 
 class PythonFeeder(object):

@@ -50,22 +50,31 @@ def resize_bilinear_u8(img, out_h, out_w):
     return np.clip(np.rint(top * (1 - wy) + bot * wy), 0, 255).astype(np.uint8)
 
 
+def _open_ale(game):
+    """-> (ALEInterface, rom path) from whichever ALE binding is installed."""
+    backend = _find_ale()
+    if backend is None:
+        raise ImportError("AtariEnv needs ale_py or atari_py; neither is installed")
+    if backend == "atari_py":
+        import atari_py
+        return atari_py.ALEInterface(), atari_py.get_game_path(game)
+    import ale_py
+    import ale_py.roms as roms
+    return ale_py.ALEInterface(), getattr(roms, game.capitalize())
+
+
 class AtariEnv(Env):
-    def __init__(self, args, process_ind=0, num_envs_per_process=1):
+    """`ale` may be any object with the ALEInterface methods used here (setInt/setFloat/setBool, loadROM,
+    getMinimalActionSet, act, game_over, lives, reset_game, getScreenGrayscale, getScreenRGB): the tests drive
+    the wrapper with a scripted one (tests/test_atari_env.py), production passes None and opens the emulator."""
+
+    def __init__(self, args, process_ind=0, num_envs_per_process=1, ale=None):
         super().__init__(args, process_ind, num_envs_per_process)
         assert self.num_envs_per_process == 1
-        backend = _find_ale()
-        if backend is None:
-            raise ImportError("AtariEnv needs ale_py or atari_py; neither is installed")
-        if backend == "atari_py":
-            import atari_py
-            self.ale = atari_py.ALEInterface()
-            rom = atari_py.get_game_path(self.game)
+        if ale is None:
+            self.ale, rom = _open_ale(self.game)
         else:
-            import ale_py
-            self.ale = ale_py.ALEInterface()
-            import ale_py.roms as roms
-            rom = getattr(roms, self.game.capitalize())
+            self.ale, rom = ale, self.game
         self.ale.setInt("random_seed", self.seed)
         self.ale.setInt("max_num_frames", self.early_stop)
         self.ale.setFloat("repeat_action_probability", 0)   # sticky actions off
@@ -112,6 +121,24 @@ class AtariEnv(Env):
     @property
     def action_space(self):
         return len(self.actions)
+
+    def render(self):
+        """Show the emulator's RGB screen (reference atari_env.py:82-84); a no-op without OpenCV / a display."""
+        try:
+            import cv2
+            cv2.imshow("screen", self.ale.getScreenRGB()[:, :, ::-1])
+            cv2.waitKey(1)
+            return True
+        except Exception:
+            return False
+
+    def close(self):
+        """reference atari_env.py:86-87"""
+        try:
+            import cv2
+            cv2.destroyAllWindows()
+        except Exception:
+            pass
 
     def step(self, action):
         self.exp_action = self._preprocess_action(action)

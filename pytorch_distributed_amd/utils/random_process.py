@@ -2,14 +2,12 @@
 
 Capability parity with reference utils/random_process.py:10-49: an annealed
 Gaussian base and the Ornstein-Uhlenbeck process the DDPG actor uses
-(theta=0.15, sigma=0.3).  `VecOrnsteinUhlenbeck` is the batched variant used by
-the GPU actor pool: one state row per env, sampled with a torch Generator on
-whatever device the inference server runs on.
+(theta=0.15, sigma=0.3).  An actor process that steps several envs
+(agents/actors.py: one _EnvWorker per env) gives each env its own process.
 """
 import math
 
 import numpy as np
-import torch
 
 
 class RandomProcess(object):
@@ -53,24 +51,3 @@ class OrnsteinUhlenbeckProcess(AnnealedGaussianProcess):
 
     def reset_states(self):
         self.x_prev = np.array(self.x0, dtype=np.float64) if self.x0 is not None else np.zeros(self.size)
-
-
-class VecOrnsteinUhlenbeck(object):
-    """OU noise for `num_envs` environments at once, state kept on `device`."""
-
-    def __init__(self, num_envs, size, theta=0.15, mu=0.0, sigma=0.3, dt=1e-2, device="cpu", seed=0):
-        self.theta, self.mu, self.sigma, self.dt = theta, mu, sigma, dt
-        self.x = torch.zeros(num_envs, size, device=device)
-        self.gen = torch.Generator(device=device)
-        self.gen.manual_seed(seed)
-
-    def sample(self):
-        eps = torch.randn(self.x.shape, device=self.x.device, generator=self.gen)
-        self.x += self.theta * (self.mu - self.x) * self.dt + self.sigma * math.sqrt(self.dt) * eps
-        return self.x
-
-    def reset_states(self, env_ids=None):
-        if env_ids is None:
-            self.x.zero_()
-        else:
-            self.x[env_ids] = 0.0

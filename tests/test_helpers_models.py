@@ -3,7 +3,7 @@ import pytest
 import torch
 
 from pytorch_distributed_amd.utils.helpers import Experience, reset_experience, update_target_model
-from pytorch_distributed_amd.utils.random_process import OrnsteinUhlenbeckProcess, VecOrnsteinUhlenbeck
+from pytorch_distributed_amd.utils.random_process import OrnsteinUhlenbeckProcess
 from pytorch_distributed_amd.utils.checkpoint import save_state_dict, load_state_dict
 from pytorch_distributed_amd.utils.options import Options
 from pytorch_distributed_amd.models.dqn_cnn_model import DqnCnnModel
@@ -133,5 +133,3 @@ def test_ou_process_statistics():
     assert p.current_sigma == 0.3       # sigma_min=None: never anneals (reference quirk)
     p.reset_states()
     assert p.x_prev[0] == 0
-    v = VecOrnsteinUhlenbeck(4, 2)
-    assert v.sample().shape == (4, 2)

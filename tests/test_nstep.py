@@ -4,7 +4,7 @@ step index, so every emitted transition can be checked by value."""
 import numpy as np
 import pytest
 
-from pytorch_distributed_amd.agents.nstep import NStepAssembler, nstep_batch_returns
+from pytorch_distributed_amd.agents.nstep import NStepAssembler
 from pytorch_distributed_amd.agents.actors import actor_epsilon
 
 
@@ -89,11 +89,6 @@ def test_epsilon_ladder():
     assert vals[0] == pytest.approx(0.4) and vals[-1] == pytest.approx(0.4 ** 8)
     for i, v in enumerate(vals):
         assert v == pytest.approx(0.4 ** (1 + 7 * i / (n - 1)))
-
-
-def test_batch_returns():
-    r, g = nstep_batch_returns(np.array([[1.0, 2.0, 3.0]]), 0.5)
-    assert r[0] == pytest.approx(1 + 1 + 0.75) and g == pytest.approx(0.125)
 
 
 @pytest.mark.parametrize("nstep,per,dtype", [(1, False, "uint8"), (5, True, "uint8"), (3, True, "float32")])
