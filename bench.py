@@ -71,11 +71,15 @@ def parse_args(argv=None):
     ap.add_argument("--graph-steps", type=int, default=None,
                     help="learner updates per hipGraph replay (default: the option's, 5; 1 = one graph per step)")
     ap.add_argument("--actor-bench", action="store_true", help="also time batched actor inference (untimed extra)")
-    ap.add_argument("--node", action="store_true",
-                    help="also run the whole job (logger + actors + learner + evaluator) for a bounded time and "
-                         "report env frames/s + learner updates/s measured inside it")
-    ap.add_argument("--node-steps", type=int, default=60000, help="learner steps of the --node job")
+    ap.add_argument("--node", default="auto", choices=["auto", "on", "off"],
+                    help="after the timed learner windows, also run the whole job (logger + actors + inference server + "
+                         "learner + evaluator, bench/node_throughput.py) for a bounded number of learner steps and "
+                         "report env frames/s + learner updates/s measured inside it under \"node\" "
+                         "(auto: on a GPU with --gpus 1)")
+    ap.add_argument("--node-steps", type=int, default=40000, help="learner steps of the --node job")
     ap.add_argument("--node-actors", type=int, default=8)
+    ap.add_argument("--node-envs-per-actor", type=int, default=2)
+    ap.add_argument("--node-timeout", type=float, default=240.0)
     ap.add_argument("--launcher", action="store_true", help="start the rank(s) as child processes even for --gpus 1")
     ap.add_argument("--launch-timeout", type=float, default=900.0)
     return ap.parse_args(argv)
@@ -158,6 +162,39 @@ def launch_ranks(a, argv):
 def _median(xs):
     s = sorted(xs)
     return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
+
+
+def run_node_job(a, precision, device):
+    """bench/node_throughput.py as a child process (its launcher spawns the job's processes); -> its JSON dict,
+    or {"error": ...}: the learner number of this bench stays valid whatever happens here."""
+    import signal
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench", "node_throughput.py"), "--config", str(a.config),
+           "--steps", str(a.node_steps), "--actors", str(a.node_actors),
+           "--envs-per-actor", str(a.node_envs_per_actor), "--precision", precision,
+           "--device", "cuda" if str(device).startswith("cuda") else "cpu"]
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT,
+                             start_new_session=True)
+        try:
+            stdout, _ = p.communicate(timeout=a.node_timeout)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)        # the session this call started, nothing else
+            p.communicate()
+            return {"error": "node job did not finish within %.0f s" % a.node_timeout}
+        for line in reversed(stdout.splitlines()):
+            if line.startswith("{"):
+                d = json.loads(line)
+                keep = ("num_actors", "num_envs_per_actor", "actor_inference", "precision", "learner_steps", "wall_s",
+                        "learner_updates_per_sec_steady", "env_frames_per_sec_mean", "env_frames_per_sec_peak",
+                        "actor_steps_per_sec_mean", "inference", "exitcodes", "actor_restarts", "env", "memory")
+                d = {k: d.get(k) for k in keep}
+                d["env_frames_per_sec"] = d.pop("env_frames_per_sec_mean")
+                d["learner_updates_per_sec_in_job"] = d.pop("learner_updates_per_sec_steady")
+                return d
+        return {"error": "node job printed no result (exit %s)" % p.returncode}
+    except Exception as exc:
+        return {"error": repr(exc)}
 
 
 def timed_windows(core, comm, steps, min_time, max_windows, sync, reduce_max):
@@ -369,17 +406,14 @@ def run_rank(a):
     if hasattr(memory, "close"):
         memory.close()
     comm.close()
-    if a.node and rank == 0:
+    node_on = a.node == "on" or (a.node == "auto" and use_cuda and world == 1)
+    if node_on and rank == 0:
         # whole-job metric (BASELINE.json: learner updates/s + env frames/s of the node): the launcher-run job
-        # of config 2, in child processes; this rank's GPU work is over and its replay is released
+        # of config 2 in child processes; this rank's GPU work is over and its replay is released
         del memory
         if use_cuda:
             torch.cuda.empty_cache()
-        from bench.node_throughput import run_job
-        try:
-            out["node"] = run_job(config=a.config, actors=a.node_actors, steps=a.node_steps)
-        except Exception as exc:        # the learner number above stays valid
-            out["node"] = {"error": repr(exc)}
+        out["node"] = run_node_job(a, precisions[0], device)
     if rank == 0:
         print(json.dumps(out), flush=True)
 

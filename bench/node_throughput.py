@@ -34,6 +34,11 @@ def main():
     ap.add_argument("--learn-start", type=int, default=None)
     ap.add_argument("--inference", default=None, choices=[None, "local", "batched"])
     ap.add_argument("--device", default=None)
+    ap.add_argument("--envs-per-actor", type=int, default=None,
+                    help="envs stepped by each actor process (2 = one inference request in flight while the other "
+                         "env is stepped)")
+    ap.add_argument("--window-us", type=int, default=None, help="inference batching window (option inference_window_us)")
+    ap.add_argument("--precision", default=None, choices=[None, "fp32", "bf16"])
     ap.add_argument("--set", nargs="*", default=[], help="extra KEY=VALUE option overrides")
     a = ap.parse_args()
 
@@ -60,6 +65,12 @@ def main():
         ov["actor_inference"] = a.inference
     if a.device is not None:
         ov["device"] = a.device
+    if a.envs_per_actor is not None:
+        ov["num_envs_per_actor"] = a.envs_per_actor
+    if a.window_us is not None:
+        ov["inference_window_us"] = a.window_us
+    if a.precision is not None:
+        ov["precision"] = a.precision
     ov.update(parse_overrides(a.set))
     opt = Options(config=a.config, overrides=ov)
 
@@ -79,11 +90,18 @@ def main():
         busy = busy[:-1]
     frame_mult = 4 if opt.env_type in ("atari", "synthetic") else 1
     steps_per_s = [v for _, _, v in fps if v > 0]
+    infer = None
+    try:
+        with open(os.path.join(opt.log_dir, "inference_stats.json")) as f:
+            infer = json.load(f)
+    except (OSError, ValueError):
+        pass
     out = {
         "bench": "node_throughput", "config": a.config, "agent": opt.agent_type, "env": opt.env_type,
         "model": opt.model_type, "memory": opt.memory_type, "num_actors": opt.num_actors,
+        "num_envs_per_actor": opt.num_envs_per_actor,
         "num_learners": opt.num_learners, "actor_inference": opt.actor_inference, "device": opt.device,
-        "compute": opt.compute, "batch_size": opt.agent_params.batch_size, "nstep": opt.agent_params.nstep,
+        "compute": opt.compute, "precision": opt.precision, "inference": infer, "batch_size": opt.agent_params.batch_size, "nstep": opt.agent_params.nstep,
         "learner_steps": a.steps, "wall_s": round(wall, 1),
         "learner_updates_per_sec_steady": round(sum(busy) / len(busy), 1) if busy else None,
         "learner_updates_per_sec_peak": round(max([v for _, _, v in ups] or [0]), 1),

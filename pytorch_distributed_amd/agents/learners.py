@@ -15,6 +15,7 @@ What changed relative to the reference:
 `DqnTorchCore` / `DdpgTorchCore` hold the per-step arithmetic so tests and the
 benchmark can drive it without processes.
 """
+import os
 import time
 
 import numpy as np
@@ -262,6 +263,50 @@ def _host_inference(args, core, model, mailbox, device):
     return server
 
 
+def _verify_learner_ranks(args, comm, rank, members):
+    """num_learners=N must mean N distinct ranks in ONE collective group, on N distinct GPUs when on GPUs: the same
+    proof bench.py prints (MIN / MAX / SUM of the rank ids, all-gather of rank / device / pid; parallel/comm.py
+    verify_ranks), written to <log_dir>/learner_ranks.json by rank 0.  Ranks that wrapped onto one GPU (more
+    learners than devices) are refused unless `allow_shared_gpu` is set (one-GPU rehearsals)."""
+    import json
+    facts = comm.verify_ranks()
+    bad = None
+    world = args.num_learners
+    if facts["rccl_ranks"] != members or not facts["ranks_distinct"]:
+        bad = "num_learners=%d: expected %d group members, the group has %d (distinct: %s)" % (
+            world, members, facts["rccl_ranks"], facts["ranks_distinct"])
+    elif (args.device == "cuda" and not getattr(args, "allow_shared_gpu", False)
+          and len(set((r["device_index"], r["device_uuid_hash"]) for r in facts["rank_devices"][:world])) < world):
+        bad = ("num_learners=%d learner ranks share a GPU (%d visible); set allow_shared_gpu=True for a rehearsal"
+               % (world, torch.cuda.device_count()))
+    if rank == 0:
+        os.makedirs(args.log_dir, exist_ok=True)
+        with open(os.path.join(args.log_dir, "learner_ranks.json"), "w") as f:
+            json.dump(facts, f)
+        print("[learner] %d ranks verified over %s: ids min/max/sum %s, devices %s"
+              % (facts["rccl_ranks"], facts["collective_backend"], facts["rank_id_min_max_sum"],
+                 [(r["rank"], r["device_index"]) for r in facts["rank_devices"]]), flush=True)
+    if bad:
+        raise RuntimeError(bad)
+
+
+def _report_rank_agreement(args, comm, core, rank, step):
+    """After the last step every rank must hold the same parameters (synchronous DP): max |rank r - rank 0|."""
+    import json
+    try:
+        mine = core.flat_params().detach().float().clone()
+        ref = mine.clone()
+        comm.broadcast_(ref, src=0)
+        diff = (mine - ref).abs().max().reshape(1)
+        diff = float(comm.all_reduce_sum_(diff).item())         # >= 0 on every rank: the sum is 0 iff all are
+        if rank == 0:
+            with open(os.path.join(args.log_dir, "learner_rank_agreement.json"), "w") as f:
+                json.dump({"steps": step, "param_max_abs_diff_summed_over_ranks": diff}, f)
+            print("[learner] after %d steps: sum over ranks of max |param(rank r) - param(rank 0)| = %.3g" % (step, diff), flush=True)
+    except Exception as exc:        # a report, never a reason to fail the shutdown
+        print("[learner] rank agreement report failed: %r" % (exc,), flush=True)
+
+
 def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
                   global_memory, global_model, global_optimizer, kind):
     print("---------------------------->", process_ind, "learner")
@@ -282,6 +327,9 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
     collective_sync = resolve_weight_sync(args) == "collective"
     comm = make_comm(rank, world, local_device, port=getattr(args, "dist_port", None),
                      extra_ranks=1 if collective_sync else 0)
+
+    if world > 1:       # (with collective weight sync the inference rank is the group's last member and joins in)
+        _verify_learner_ranks(args, comm, rank, world + (1 if collective_sync else 0))
 
     def build():
         return model_prototype(args.model_params, args.norm_val, args.state_shape,
@@ -383,6 +431,8 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
         if bcast_pub is not None:
             bcast_pub.publish(core.flat_params())
             bcast_pub.close()
+    if world > 1 and not collective_sync:
+        _report_rank_agreement(args, comm, core, rank, step)
     if hasattr(global_memory, "close"):
         global_memory.close()
     if hosted is not None:
@@ -391,6 +441,8 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
         st = hosted.stats()
         print("[inference@learner] %d requests in %d batches (mean %.1f per batch, %.0f us per batch)"
               % (st["requests"], st["batches"], st["mean_batch"], st["mean_batch_us"]), flush=True)
+        from ..parallel.inference_server import write_inference_stats
+        write_inference_stats(args, st, "learner")
         hosted.close()
     comm.close()
 

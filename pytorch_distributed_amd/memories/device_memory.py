@@ -35,6 +35,7 @@ class DeviceMemory(Memory):
         self.codec = TransitionCodec(self.state_shape, self.state_dtype, self.action_shape, self.reward_shape)
         self.ring = ShmRing(int(getattr(args, "ingest_ring_slots", 4096)), self.codec.record_bytes)
         self.ingest_chunk = int(getattr(args, "ingest_chunk", 256))
+        self.ingest_device_slabs = int(getattr(args, "ingest_device_slabs", 32))
         self.shared_size = mp.Value("l", 0)     # rank 0's resident transitions, visible to every process
         self.total_fed = mp.Value("l", 0)
         self.attached = False
@@ -99,6 +100,22 @@ class DeviceMemory(Memory):
                 self.staging_evt.append(None)
             self.staging.append(host)
         self._stage_next = 0
+        # Pumped path: the H2D copies run on a stream of their own, so a pinned buffer is free again as soon as its
+        # DMA is done -- NOT after the learner stream, which the host keeps up to ~100 updates (tens of ms) ahead of
+        # the GPU, has reached it: with 4 x 256 records in flight per such latency the actors were throttled to
+        # ~32 k transitions/s (profiles/r2_node_*.json).  Only the unpack kernel is ordered into the learner stream
+        # (rows change between two updates, never under one); it reads from a pool of device slabs (0.46 GB of the
+        # 288 GB) that are recycled once their unpack has run.
+        self._copy_stream = None
+        self._slabs, self._slab_free, self._slab_busy = [], [], []
+        if dev.type == "cuda":
+            self._copy_stream = torch.cuda.Stream(device=dev)
+            nslab = max(2, self.ingest_device_slabs)
+            self._slabs = [torch.zeros(self.ingest_chunk, c.record_bytes, dtype=torch.uint8, device=dev)
+                           for _ in range(nslab)]
+            self._slab_free = list(range(nslab))
+            self._copy_evt = [torch.cuda.Event() for _ in range(nslab)]
+            self._unpack_evt = [torch.cuda.Event() for _ in range(nslab)]
         # GPU replay: a native pump thread fills the pinned buffers (parallel/csrc/shm_ring.cpp), the
         # learner thread only enqueues DMAs.  Host replay keeps the simple in-line pop.
         self.pump = None
@@ -176,21 +193,28 @@ class DeviceMemory(Memory):
         import ctypes
         from ..parallel import hostlib
         L = hostlib.lib()
-        while self._in_flight and self._in_flight[0][1].query():        # give finished buffers back
+        while self._in_flight and self._in_flight[0][1].query():        # DMA done: the pinned buffer goes back
             L.pda_pump_release(self.pump, self._in_flight.pop(0)[0])
+        while self._slab_busy and self._unpack_evt[self._slab_busy[0]].query():     # unpacked: the slab is free
+            self._slab_free.append(self._slab_busy.pop(0))
         moved = 0
+        learner_stream = torch.cuda.current_stream(self.device)
         for _ in range(max_chunks):
+            if not self._slab_free:
+                break               # every slab waits for the learner stream: back-pressure on the ring
             i = L.pda_pump_take(self.pump, ctypes.byref(self._pump_n))
             if i < 0:
                 break
             n = self._pump_n.value
-            self.staging_dev[i][:n].copy_(self.staging[i][:n], non_blocking=True)
-            evt = self.staging_evt[i]
-            if evt is None:
-                evt = self.staging_evt[i] = torch.cuda.Event()
-            evt.record()
-            self._in_flight.append((i, evt))
-            self.ingest_records(self.staging_dev[i], n)
+            d = self._slab_free.pop(0)
+            with torch.cuda.stream(self._copy_stream):
+                self._slabs[d][:n].copy_(self.staging[i][:n], non_blocking=True)
+                self._copy_evt[d].record()
+            self._in_flight.append((i, self._copy_evt[d]))
+            learner_stream.wait_event(self._copy_evt[d])
+            self.ingest_records(self._slabs[d], n)
+            self._unpack_evt[d].record(learner_stream)
+            self._slab_busy.append(d)
             moved += n
         return moved
 

@@ -53,9 +53,11 @@ struct InferConfig {
     unsigned long long seed;
     int high_priority;
     int max_bucket;             // 0: nslots rounded up
+    int window_us;              // batching window of the loop thread: once a request is pending, wait up to this long
+                                // for the other live slots to post theirs (0: answer whatever is pending at once)
 };
 
-struct Stats { unsigned long long batches, requests, busy_ns, max_batch, registered, idle_polls; };
+struct Stats { unsigned long long batches, requests, busy_ns, max_batch, registered, idle_polls, window_ns, live_slots; };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     std::fprintf(stderr, "[pda infer] %s failed: %s\n", #x, hipGetErrorString(e_)); ok = false; } } while (0)
@@ -82,7 +84,8 @@ struct Server {
     // loop
     std::thread thread;
     std::atomic<bool> stop{false};
-    std::atomic<unsigned long long> batches{0}, requests{0}, busy_ns{0}, max_batch{0}, idle_polls{0};
+    std::atomic<unsigned long long> batches{0}, requests{0}, busy_ns{0}, max_batch{0}, idle_polls{0}, window_ns{0};
+    std::atomic<unsigned long long> live_slots{0};
     std::vector<int> ids;
     std::vector<uint64_t> req_seen;
 };
@@ -243,11 +246,37 @@ bool build(Server& S) {
     return ok;
 }
 
+// Slots that have posted at least one request: what a full batch is measured against.
+int live_slots(Server& S) {
+    int live = 0;
+    for (int s = 0; s < S.c.nslots; ++s)
+        live += pda_mailbox::req_word(S.c.seq, s)->load(std::memory_order_relaxed) > 0 ? 1 : 0;
+    return live;
+}
+
 // One poll of the mailbox.  Returns the number of requests answered (0: nothing pending, -1: GPU error).
-int serve_once(Server& S) {
+// window_us > 0: a partial batch waits that long (polling) for the rest of the live slots -- a batch of 8 costs the
+// GPU and the host what a batch of 4 does (launch-bound), so when the server is the busy party, answering half the
+// actors twice as often is the slower way round.
+int serve_once(Server& S, int window_us = 0) {
     InferConfig& c = S.c;
     int n = pda_mailbox::collect_pending(c.seq, c.nslots, S.ids.data(), S.req_seen.data(), S.buckets.back());
     if (n == 0) return 0;
+    if (window_us > 0) {
+        int want = live_slots(S);
+        S.live_slots.store((unsigned long long)want, std::memory_order_relaxed);
+        if (n < want) {
+            auto w0 = std::chrono::steady_clock::now();
+            auto deadline = w0 + std::chrono::microseconds(window_us);
+            while (n < want && std::chrono::steady_clock::now() < deadline &&
+                   !S.stop.load(std::memory_order_relaxed)) {
+                for (int i = 0; i < 16; ++i) pda_mailbox::cpu_relax();
+                n = pda_mailbox::collect_pending(c.seq, c.nslots, S.ids.data(), S.req_seen.data(), S.buckets.back());
+            }
+            S.window_ns.fetch_add((unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                                      std::chrono::steady_clock::now() - w0).count(), std::memory_order_relaxed);
+        }
+    }
     auto t0 = std::chrono::steady_clock::now();
     bool& ok = S.ok;
     size_t bi = 0;
@@ -297,7 +326,7 @@ void loop(Server* S, int device) {
     (void)hipSetDevice(device);
     int idle = 0;
     while (!S->stop.load(std::memory_order_acquire)) {
-        int n = serve_once(*S);
+        int n = serve_once(*S, S->c.window_us);
         if (n < 0) break;
         if (n > 0) { idle = 0; continue; }
         ++idle;
@@ -347,6 +376,8 @@ PDA_EXPORT void pda_infer_stats(void* h, Stats* out) {
     out->max_batch = S->max_batch.load();
     out->registered = S->registered ? 1 : 0;
     out->idle_polls = S->idle_polls.load();
+    out->window_ns = S->window_ns.load();
+    out->live_slots = S->live_slots.load();
 }
 PDA_EXPORT void pda_infer_destroy(void* h) {
     Server* S = static_cast<Server*>(h);

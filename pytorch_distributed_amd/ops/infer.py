@@ -31,12 +31,13 @@ class _InferConfig(ctypes.Structure):      # mirrors InferConfig in csrc/infer_s
                 ("D", ctypes.c_int), ("Dp", ctypes.c_int), ("H1", ctypes.c_int), ("H1p", ctypes.c_int),
                 ("H2", ctypes.c_int), ("H2p", ctypes.c_int), ("Ap", ctypes.c_int),
                 ("w", _vp * 5), ("b", _vp * 5),
-                ("seed", ctypes.c_ulonglong), ("high_priority", ctypes.c_int), ("max_bucket", ctypes.c_int)]
+                ("seed", ctypes.c_ulonglong), ("high_priority", ctypes.c_int), ("max_bucket", ctypes.c_int),
+                ("window_us", ctypes.c_int)]
 
 
 class _Stats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_ulonglong) for n in ("batches", "requests", "busy_ns", "max_batch", "registered",
-                                                  "idle_polls")]
+                                                  "idle_polls", "window_ns", "live_slots")]
 
 
 _ready = False
@@ -63,7 +64,8 @@ def _L():
 
 
 class NativeInferenceServer(object):
-    def __init__(self, mailbox, device, seed=0, high_priority=False):
+    def __init__(self, mailbox, device, seed=0, high_priority=False, window_us=0):
+        self.window_us = int(window_us)
         self.mailbox = mailbox
         self.device = torch.device(device)
         self.seed = int(seed)
@@ -88,6 +90,7 @@ class NativeInferenceServer(object):
         cfg.seed = (self.seed * 2654435761 + 97) & 0xFFFFFFFFFFFF
         cfg.high_priority = 1 if self.high_priority else 0
         cfg.max_bucket = 0
+        cfg.window_us = self.window_us
         return cfg
 
     def _create(self, cfg):
@@ -169,6 +172,7 @@ class NativeInferenceServer(object):
         d = {n: int(getattr(st, n)) for n, _ in _Stats._fields_}
         d["mean_batch"] = d["requests"] / max(d["batches"], 1)
         d["mean_batch_us"] = d["busy_ns"] / 1e3 / max(d["batches"], 1)
+        d["mean_window_us"] = d["window_ns"] / 1e3 / max(d["batches"], 1)
         return d
 
     def close(self):
@@ -180,16 +184,17 @@ class NativeInferenceServer(object):
 def make_native_server(args, model, mailbox, device, high_priority=False, weights=None):
     """Server for the configured model family, or None when the family has no native program
     (the caller then serves from Python)."""
+    window_us = int(getattr(args, "inference_window_us", 0))
     if args.model_type == "dqn-cnn":
         from .dqn_engine import CnnGeometry, CnnWeights
         geom = CnnGeometry(model.input_dims, model.output_dims, model.critic[1][0].out_features)
         w = weights if weights is not None else CnnWeights(model, geom, with_grad=False)
-        return NativeInferenceServer(mailbox, device, seed=args.seed + 4242,
-                                     high_priority=high_priority).build_cnn(w, geom, model.norm_val, model)
+        return NativeInferenceServer(mailbox, device, seed=args.seed + 4242, high_priority=high_priority,
+                                     window_us=window_us).build_cnn(w, geom, model.norm_val, model)
     if args.model_type == "ddpg-mlp":
         from .mlp_engine import DDPG_LAYERS, MlpWeights
         w = weights if weights is not None else MlpWeights(model, DDPG_LAYERS, with_grad=False,
                                                            fp32_only=("critic.1.2",))
-        return NativeInferenceServer(mailbox, device, seed=args.seed + 4242,
-                                     high_priority=high_priority).build_ddpg_actor(w, model)
+        return NativeInferenceServer(mailbox, device, seed=args.seed + 4242, high_priority=high_priority,
+                                     window_us=window_us).build_ddpg_actor(w, model)
     return None

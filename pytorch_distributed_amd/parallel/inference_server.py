@@ -171,6 +171,22 @@ class BatchedPolicy(object):
         return act.float().cpu().numpy(), z, z
 
 
+def write_inference_stats(args, st, where):
+    """Leave the serving counters where the parent (bench.py --node, bench/node_throughput.py) can read them."""
+    import json
+    import os
+    try:
+        os.makedirs(args.log_dir, exist_ok=True)
+        keep = {k: st[k] for k in ("requests", "batches", "mean_batch", "max_batch", "mean_batch_us", "mean_window_us",
+                                   "live_slots", "registered") if k in st}
+        keep["where"] = where
+        keep["window_us"] = int(getattr(args, "inference_window_us", 0))
+        with open(os.path.join(args.log_dir, "inference_stats.json"), "w") as f:
+            json.dump(keep, f)
+    except OSError:
+        pass
+
+
 def resolve_placement(args):
     """Where the batched policy runs: "learner" = a native loop thread inside learner rank 0 (shares
     the learner's live weights, high-priority stream), "process" = a process of its own."""
@@ -208,6 +224,8 @@ def inference_server(process_ind, args, global_logs, model_prototype, global_mod
         from .comm import make_comm
         comm = make_comm(args.num_learners, args.num_learners, device, port=getattr(args, "dist_port", None),
                          extra_ranks=1)
+        if args.num_learners > 1:
+            comm.verify_ranks()     # the learners' membership check is a collective of the whole group (agents/learners.py)
         receiver = WeightReceiver(comm, model.flatten_(with_grad=False).numel(), device)
     try:
         native = _native_server(args, model, mailbox, device)
@@ -246,10 +264,24 @@ def _serve_native(args, global_logs, global_model, native, version, poll_s=0.02,
         print("[inference] %d requests in %d batches (mean %.1f / max %d per batch, %.0f us per batch, "
               "zero-copy mailbox: %s)" % (st["requests"], st["batches"], st["mean_batch"], st["max_batch"],
                                           st["mean_batch_us"], bool(st["registered"])), flush=True)
+        write_inference_stats(args, st, "process")
         native.close()
 
 
 def _serve(args, global_logs, global_model, mailbox, model, policy, device, version, receiver=None, process_ind=0):
+    """Python serving loop (CPU runs, model families without a native program)."""
+    stats = {"requests": 0, "batches": 0, "busy": 0.0, "max_batch": 0}
+    try:
+        _serve_loop(args, global_logs, global_model, mailbox, model, policy, device, version, receiver, process_ind,
+                    stats)
+    finally:
+        st = {"requests": stats["requests"], "batches": stats["batches"], "max_batch": stats["max_batch"],
+              "mean_batch": stats["requests"] / max(stats["batches"], 1),
+              "mean_batch_us": 1e6 * stats["busy"] / max(stats["batches"], 1), "registered": 0}
+        write_inference_stats(args, st, "process-python")
+
+
+def _serve_loop(args, global_logs, global_model, mailbox, model, policy, device, version, receiver, process_ind, stats):
     eps_dev = None
     served, last_sync = 0, 0
     idle = 0
@@ -264,6 +296,7 @@ def _serve(args, global_logs, global_model, mailbox, model, policy, device, vers
             time.sleep(2e-5 if idle < 200 else 5e-4)
             continue
         idle = 0
+        t0 = time.time()
         obs = mailbox.obs[torch.as_tensor(ids)]
         if device.type == "cuda":
             obs = obs.pin_memory().to(device, non_blocking=True)
@@ -273,6 +306,10 @@ def _serve(args, global_logs, global_model, mailbox, model, policy, device, vers
         actions, q, mq = policy.act(obs, eps)
         mailbox.respond(ids, req_seen, actions, q, mq)
         served += len(ids)
+        stats["requests"] += len(ids)
+        stats["batches"] += 1
+        stats["busy"] += time.time() - t0
+        stats["max_batch"] = max(stats["max_batch"], len(ids))
         if served - last_sync >= args.agent_params.actor_sync_freq:
             if receiver is not None:
                 if receiver.poll_into(model.flat_params):

@@ -128,6 +128,8 @@ class Params(object):
         self.device = _default_device()     # learner / inference device: "cuda" | "cpu"
         self.actor_inference = "local"      # "local": per-actor model copy | "batched": GPU inference server
         self.inference_placement = "auto"   # batched inference runs in a "process" of its own | inside the "learner"
+        self.inference_window_us = 40       # native batched inference: a partial batch waits this long for the other live
+                                            # envs' requests (0: answer at once); measured in profiles/r2_node_*.json
         self.resume = False                 # continue from ./models/MACHINE_TIMESTAMP.resume.pth (optimizer, target, counters)
         self.resume_freq = 0                # also write the resume sidecar every this many learner steps (0: only at the end)
         self.save_resume = True
@@ -150,6 +152,7 @@ class Params(object):
         self.shutdown_grace_s = 20.0        # time the remaining processes get once the job is over, before terminate()
         self.stop_agree_every = 64          # several learner ranks: they agree on leaving the loop every this many steps
         self.ingest = "ring"                # "ring": lock-free shm ring into device replay | "direct"
+        self.allow_shared_gpu = False       # num_learners > visible GPUs: refuse (False) or let ranks share a card (rehearsal)
         self.force_dp = False               # run the data-parallel step program even with one learner (rehearsal)
         self.graph_steps = 5                # native DQN learner, HBM replay, one rank: updates per hipGraph replay (the
                                             # learner runs up to graph_steps - 1 updates ahead of its step counter)
@@ -215,6 +218,7 @@ class MemoryParams(Params):
         self.replay_device = _default_device() if "device" in self.memory_type else "cpu"
         self.ingest_ring_slots = 4096   # transitions buffered in the shm ring
         self.ingest_chunk = 256         # max transitions moved to HBM per drain
+        self.ingest_device_slabs = 32   # device-side chunks in flight between their H2D copy and the unpack kernel
 
 
 class ModelParams(Params):

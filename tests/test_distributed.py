@@ -202,6 +202,13 @@ def test_two_learner_job_through_launcher(tmp_root):
     sup = run(opt)
     assert all(c == 0 for c in sup.exitcodes), sup.exitcodes
     assert os.path.exists(opt.model_name)
+    # the job itself proved that two distinct learner ranks met in one group, and that they ended in step
+    import json
+    facts = json.load(open(os.path.join(opt.log_dir, "learner_ranks.json")))
+    assert facts["rccl_ranks"] == 2 and facts["ranks_distinct"] and facts["rank_id_min_max_sum"] == [0, 1, 1]
+    assert len(set(r["pid"] for r in facts["rank_devices"])) == 2
+    agree = json.load(open(os.path.join(opt.log_dir, "learner_rank_agreement.json")))
+    assert agree["steps"] == 25 and agree["param_max_abs_diff_summed_over_ranks"] == 0.0
 
 
 def test_ddpg_dp_equivalence_fake_comm():
