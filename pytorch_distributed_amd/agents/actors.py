@@ -136,7 +136,14 @@ def _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model
             if mailbox is not None:
                 mailbox.set_epsilon(index, eps)
         else:
-            random_process = ap.random_process(size=args.action_space, theta=0.15, sigma=0.3,
+            x0 = None
+            if getattr(ap, "ou_stationary_start", False):
+                # start the OU state at its stationary spread sigma / sqrt(2 theta) instead of 0 (the reference's):
+                # from 0 the noise is ~0.03 sqrt(t), so with N actors the first learn_start transitions all carry
+                # |action| << 1, the critic has no idea of Q's shape along the action axis, and the tanh actor runs
+                # into saturation in whichever direction the first gradients point (measured: tools/probes/ddpg_recipe.py)
+                x0 = rng.normal(0.0, 0.3 / np.sqrt(2 * 0.15), size=args.action_space)
+            random_process = ap.random_process(size=args.action_space, theta=0.15, sigma=0.3, x0=x0,
                                                n_steps_annealing=mp_.memory_size * 100)
         feeder = make_feeder(global_memory, ap.nstep, ap.gamma, enable_per,
                              native=getattr(args, "native_nstep", True))
@@ -152,6 +159,17 @@ def _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model
             return lambda state: mailbox.request(w.slot, state)[2]
         return lambda state: local_model.get_action(state, True, w.eps, device=local_device, rng=rng)[2]
 
+    # optional lower bound on the replay ratio (the counterpart of the learner's max_replay_ratio): the actors wait
+    # while they are more than learn_start + learner_step / min_replay_ratio env steps in, so a slow learner (CPU
+    # runs) sees the same data-to-update ratio a fast one does.  0 = uncoupled, as in the reference.
+    min_ratio = float(getattr(ap, "min_replay_ratio", 0.0) or 0.0)
+
+    def ahead_of_learner():
+        if min_ratio <= 0:
+            return False
+        allowed = ap.learn_start + 16 * E * args.num_actors + global_logs.learner_step.value / min_ratio
+        return global_logs.actor_step.value > allowed
+
     step = 0
     pending = None
     if mailbox is not None:     # every env has one request in flight; the server batches across actors
@@ -159,6 +177,12 @@ def _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model
     global_logs.beat("actor", process_ind)
     last_beat = time.time()
     while global_logs.running(ap.steps):
+        if ahead_of_learner():
+            time.sleep(0.001)
+            if time.time() - last_beat > 1.0:
+                global_logs.beat("actor", process_ind)
+                last_beat = time.time()
+            continue
         for j, w in enumerate(workers):
             if mailbox is not None:
                 action, qvalue, max_qvalue = mailbox.wait(w.slot, pending[j])

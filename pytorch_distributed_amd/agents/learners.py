@@ -335,6 +335,10 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
         return model_prototype(args.model_params, args.norm_val, args.state_shape,
                                args.action_space, args.action_shape).to(local_device)
     local_model, local_target_model = build(), build()
+    if local_device.type == "cpu" and sum(p.numel() for p in local_model.parameters()) < 1000000:
+        # small MLPs: intra-op threads only add barriers, and on a box whose cores the actors keep busy every such
+        # barrier waits for a descheduled thread (measured: 2-16 updates/s with 8 threads, ~700/s with one)
+        torch.set_num_threads(1)
     sync_params(local_model, global_model)
     if world > 1:       # all ranks start from rank 0's weights
         comm.broadcast_(local_model.flatten_(), src=0)
@@ -404,7 +408,9 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
                 time.sleep(0.05 if hasattr(global_memory, "drain") else 1.0)
                 continue
         if max_ratio > 0:       # optional coupling of the learner to the data rate (absent in the reference)
-            behind = step - max_ratio * global_logs.actor_step.value
+            # (env steps taken before learning could start do not count: they would be paid back as one burst of
+            # updates on the first few hundred transitions -- which is what saturates the DDPG actor for good)
+            behind = step - max_ratio * max(0, global_logs.actor_step.value - ap.learn_start)
             if comm.all_agree(behind <= 0) is False:
                 time.sleep(0.0005)
                 continue

@@ -38,12 +38,10 @@ CONFIGS = [
 PRESETS = {
     1: {"num_actors": 2, "agent_params.nstep": 1, "device": "cpu"},
     2: {"num_actors": 8, "agent_params.nstep": 5, "actor_inference": "batched"},
-    # DDPG: cap the replay ratio.  The reference's learner (~350 updates/s) never outruns its 8 actors; an
-    # uncoupled 8k-updates/s learner makes thousands of updates per turnover of a 50k replay, the tanh actor
-    # collapses to a constant saturated action and never recovers (measured: bench/learning_sanity.py,
-    # BASELINE.md).  0.005 updates per env step solves Pendulum with the 50k and with the 1M HBM replay; 0.02 did while
-    # the actors made ~40k env steps/s and stopped doing so once they got 3-4x faster (the cap is relative to them).
-    3: {"num_actors": 8, "agent_params.nstep": 5, "agent_params.max_replay_ratio": 0.005},
+    # 3 = the reference's DDPG settings, untouched (lr 1e-4, 5-step targets, the actor loss's gradient left in the
+    # critic, no actor/learner coupling).  On the built-in Pendulum they do not learn -- with the fp32 torch core as
+    # little as with the native one: see row 7 and BASELINE.md "DDPG recipe".
+    3: {"num_actors": 8, "agent_params.nstep": 5},
     4: {"num_actors": 256, "actor_inference": "batched", "memory_params.memory_size": 2 * 1024 * 1024,
         "memory_params.enable_per": True, "agent_params.nstep": 5},
     5: {"num_actors": 256, "actor_inference": "batched", "memory_params.memory_size": 1024 * 1024,
@@ -51,13 +49,24 @@ PRESETS = {
     6: {"num_actors": 2, "agent_params.nstep": 3, "agent_params.learn_start": 200,
         "agent_params.batch_size": 32, "agent_params.target_model_update": 50,
         "agent_params.lr": 1e-3, "memory_params.memory_size": 5000},
-    # 7 = the DDPG recipe that solves Pendulum here (bench/learning_sanity.py): besides the ratio cap, lr 1e-3 and
-    # the critic NOT updated by the actor loss (row 3 keeps the reference's defaults: lr 1e-4 and that leak, with
-    # which neither the fp32 torch core nor the native one leaves the saturated-action plateau in 100 k steps)
-    7: {"num_actors": 8, "agent_params.nstep": 5, "agent_params.max_replay_ratio": 0.005,
-        "memory_params.memory_size": 1024 * 1024, "agent_params.learn_start": 20000,
-        "agent_params.lr": 1e-3, "agent_params.compat_ddpg_grad_leak": False,
-        "agent_params.actor_warmup_steps": 2000},
+    # 7 = the DDPG recipe that holds on Pendulum (>= -200 over the last 10 evaluations on 4 of 4 seeds, in the
+    # synchronous probe tools/probes/ddpg_recipe.py and in the asynchronous job; BASELINE.md "DDPG recipe" has the
+    # ablations).  Each deviation from row 3 is needed, none of the others tried is:
+    #   lr 1e-3 (reference 1e-4)       with 1e-4 / 3e-4 the policy is still a saturated bang-bang after 40 k updates
+    #   nstep 1 (reference 5)          uncorrected 3- and 5-step returns under OU noise: saturated actor, 0 of 2 seeds
+    #   compat_ddpg_grad_leak False    the reference adds d(-Q(s,pi(s)))/d(critic) to the critic's gradient
+    #                                  (ddpg_learner.py:68-86: no zero_grad in between): 0 of 4 seeds learn with it
+    #   replay ratio 1 +- 0, both ways one update per env step (summed over actors), counted from learn_start: a learner
+    #                                  that is 20x faster than its actors overfits the first transitions and saturates
+    #                                  the tanh actor for good; one that is slower leaves the ratio to the machine
+    #   actor_sync_freq 50 (ref. 400)  per actor: with 8 actors 400 steps are 3 200 updates of policy lag (1 of 2 seeds)
+    #   ou_stationary_start            N actors starting their OU noise at 0 fill the first learn_start transitions
+    #                                  with |a| << 1 (3 of 4 seeds without, 4 of 4 with)
+    # Not needed (measured): reward scaling, separate actor/critic rates, a larger tau, critic-only warm-up (hurts).
+    7: {"num_actors": 8, "agent_params.nstep": 1, "agent_params.lr": 1e-3,
+        "agent_params.compat_ddpg_grad_leak": False, "agent_params.max_replay_ratio": 1.0,
+        "agent_params.min_replay_ratio": 1.0, "agent_params.actor_sync_freq": 50,
+        "agent_params.ou_stationary_start": True, "memory_params.memory_size": 1024 * 1024},
 }
 
 
@@ -244,6 +253,7 @@ class AgentParams(Params):
         self.evaluator_nepisodes = 2
         self.nstep = 5
         self.max_replay_ratio = 0.0     # cap on learner updates per actor env step (0: none, as in the reference)
+        self.min_replay_ratio = 0.0     # floor on the same ratio: actors wait for the learner (0: none, as in the reference)
         self.poll_interval = 5.0        # logger/evaluator wake-up period (secs; the reference hard-codes 5)
         if self.agent_type == "dqn":
             self.clip_grad = np.inf
@@ -270,6 +280,7 @@ class AgentParams(Params):
             # the reference lets the actor loss deposit gradients into the critic
             # (ddpg_learner.py:66-86); False freezes the critic during the actor loss
             self.compat_ddpg_grad_leak = True
+            self.ou_stationary_start = False # DDPG actors: OU noise starts at its stationary spread, not at 0 (see agents/actors.py)
             self.actor_warmup_steps = 0      # DDPG: learner updates during which only the critic is trained (0: as the reference)
 
 
