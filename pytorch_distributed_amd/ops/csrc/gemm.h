@@ -32,7 +32,7 @@
 #define GEMM_BK 64          // default k-tile (elements); a template parameter of the kernel
 #define GEMM_PF 3           // k-tiles of global loads kept in flight ahead of the MFMAs (register ring)
 #define GEMM_THREADS 256
-#define GEMM_MAX_GROUPS 4
+#define GEMM_MAX_GROUPS 8
 
 // ----------------------------------------------------------------------------
 // operand sources

@@ -195,6 +195,27 @@ PDA_EXPORT void pda_linear_wgrad2(const void* const* dy, const void* const* x, v
     launch_gemm<64, 64, 2, 2>(a, 2, maxM, maxN, B, 0, stream);
 }
 
+// every weight gradient of an MLP step in ONE launch: n <= GEMM_MAX_GROUPS problems of different shapes over
+// their own row ranges (B[i] rows), single slice each.  The grid is sized for the largest; the others' surplus
+// workgroups leave at once.  (mlp_engine.py: six launches of a few kFLOP each -> one.)
+PDA_EXPORT void pda_linear_wgrad_n(int n, const void* const* dy, const void* const* x, void* const* gw,
+                                   void* const* gb, const int* B, const int* Nout, const int* Kin,
+                                   const long* lddy, const long* ldx, const long* ldg, hipStream_t stream) {
+    if (n <= 0 || n > GEMM_MAX_GROUPS) return;
+    GemmArgs<SrcDenseT, SrcDenseT, EpiWgrad> a;
+    int maxM = 0, maxN = 0, maxK = 0;
+    for (int i = 0; i < n; ++i) {
+        a.g[i].a = {(const bf16_t*)dy[i], lddy[i], Nout[i], B[i]};
+        a.g[i].b = {(const bf16_t*)x[i], ldx[i], Kin[i], B[i]};
+        a.g[i].e = {(float*)gw[i], (float*)gb[i], ldg[i], 0, 0, 1.f};
+        a.g[i].M = Nout[i]; a.g[i].N = Kin[i]; a.g[i].K = B[i];
+        maxM = Nout[i] > maxM ? Nout[i] : maxM;
+        maxN = Kin[i] > maxN ? Kin[i] : maxN;
+        maxK = B[i] > maxK ? B[i] : maxK;
+    }
+    launch_gemm<64, 64, 2, 2>(a, n, maxM, maxN, maxK, 0, stream);
+}
+
 // fc backward in one launch: the data gradient of one linear layer (pda_linear_dgrad's problem, 32-row tiles) and the
 // two single-slice weight gradients of pda_linear_wgrad2 -- independent of each other, all ready after the head.
 PDA_EXPORT void pda_fc_backward_duo(const void* d_dy, const void* d_w, const void* d_y, void* d_dx, int M, int Nout,

@@ -38,7 +38,30 @@ struct AdamExtras {
     const unsigned long long* counter;
     long shadow_plane;      // fp32-precision engines: the shadow's lo plane (bf16(w - bf16(w))) lies this many
                             // elements after the hi plane; 0 = plain bf16 shadow
+    // MLP engines (flat chunks only, C == 1 segments):
+    const int2* tinfo;      // per segment (offset, pitch) of a TRANSPOSED bf16 copy [col][row] in `shadow` that the fused
+                            // backward reads as its B operand (mlp_fused.hip); pitch 0 = none
+    float* tgt; bf16_t* tgt_shadow; float tau;      // target network updated in the same pass: tgt += tau (p - tgt),
+                                                    // with its shadow (same segment table); tgt == nullptr = off
 };
+
+// the extra copies of a freshly updated weight (see AdamExtras): e = element within segment `seg`, ip = master index
+__device__ __forceinline__ void put_extras(const AdamExtras& x, bf16_t* shadow, const SegEntry& s, int seg, int e,
+                                           long ip, long si, float w) {
+    if (x.tinfo) {
+        int2 ti = x.tinfo[seg];
+        if (ti.y > 0) {
+            int r = e / s.cols, q = e - r * s.cols;
+            shadow[(long)ti.x + (long)q * ti.y + r] = f2bf(w);
+        }
+    }
+    if (x.tgt) {
+        float t = x.tgt[ip];
+        t += x.tau * (w - t);
+        x.tgt[ip] = t;
+        if (si >= 0 && x.tgt_shadow) x.tgt_shadow[si] = f2bf(t);
+    }
+}
 
 __device__ __forceinline__ void put_shadow(bf16_t* shadow, long si, float w, long plane) {
     bf16_t h = f2bf(w);
@@ -264,6 +287,7 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
             pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
             p[ip] = pi; m[i] = mi; v[i] = vi;
             if (si >= 0) put_shadow(shadow, si, pi, x.shadow_plane);
+            put_extras(x, shadow, s, ch.x, e, ip, si, pi);
         }
         return;
     }
@@ -280,5 +304,6 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
         pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
         p[ip] = pi; m[i] = mi; v[i] = vi;
         if (si >= 0) put_shadow(shadow, si, pi, x.shadow_plane);
+        put_extras(x, shadow, s, ch.x, e, ip, si, pi);
     }
 }

@@ -77,6 +77,27 @@ class _DdpgHeadArgs(ctypes.Structure):      # mirrors DdpgHeadArgs in csrc/mlp_k
                 ("rng_counter", _vp), ("opt_step", _vp)]
 
 
+class _Layer(ctypes.Structure):             # mirrors Layer in csrc/mlp_fused.hip
+    _fields_ = [("w", _vp), ("b", _vp), ("N", ctypes.c_int), ("K", ctypes.c_int), ("Kp", ctypes.c_int)]
+
+
+class _DdpgFusedArgs(ctypes.Structure):     # mirrors DdpgFusedArgs in csrc/mlp_fused.hip
+    _fields_ = [("s0", _vp), ("s1", _vp), ("ld_s", ctypes.c_long), ("tails", _vp), ("tail_ld", ctypes.c_int),
+                ("off_action", ctypes.c_int), ("off_reward", ctypes.c_int), ("off_gamma", ctypes.c_int),
+                ("off_term", ctypes.c_int), ("idx", _vp), ("isw", _vp),
+                ("a0", _Layer * 2), ("a2", _Layer * 2), ("a4", _Layer * 2), ("c0", _Layer * 2), ("c1", _Layer * 2),
+                ("w3", _vp * 2), ("b3", _vp * 2), ("c1T", _Layer), ("a2T", _Layer),
+                ("x0", _vp), ("ld_x0", ctypes.c_long), ("ha1", _vp), ("ld_ha1", ctypes.c_long),
+                ("ha2", _vp), ("ld_ha2", ctypes.c_long), ("cat", _vp), ("ld_cat", ctypes.c_long),
+                ("h2", _vp), ("ld_h2", ctypes.c_long), ("dh2", _vp), ("dq", _vp), ("dq_ld", ctypes.c_int),
+                ("dcat", _vp), ("dha2", _vp), ("dha1", _vp),
+                ("q_out", _vp), ("td_out", _vp), ("loss_sum", _vp), ("leaf_sum", _vp), ("leaf_min", _vp),
+                ("prio_eps", ctypes.c_float), ("prio_alpha", ctypes.c_float),
+                ("B", ctypes.c_int), ("D", ctypes.c_int), ("A", ctypes.c_int), ("C1", ctypes.c_int),
+                ("leak", ctypes.c_int), ("actor_warmup", ctypes.c_int), ("rng_counter", _vp), ("opt_step", _vp),
+                ("prof", _vp)]
+
+
 _ready = False
 
 
@@ -92,6 +113,12 @@ def _L():
         L.pda_ddpg_head.restype = None
         L.pda_bf16_rows_to_f32.argtypes = [_vp, ctypes.c_long, _vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, _vp]
         L.pda_bf16_rows_to_f32.restype = None
+        L.pda_ddpg_fused.argtypes = [ctypes.POINTER(_DdpgFusedArgs), _vp]
+        L.pda_ddpg_fused.restype = None
+        L.pda_ddpg_fused_supported.argtypes = [ctypes.c_int] * 6
+        L.pda_ddpg_fused_supported.restype = ctypes.c_int
+        L.pda_linear_wgrad_n.argtypes = [ctypes.c_int] + [_vp] * 10 + [_vp]
+        L.pda_linear_wgrad_n.restype = None
         _ready = True
     return L
 
@@ -111,7 +138,9 @@ class MlpWeights(object):
     """Flat fp32 parameters of one network + zero-padded bf16 shadows [N][pad8(K)] of every
     matrix that feeds an MFMA GEMM.  Gradients/moments use the same [N][K] order."""
 
-    def __init__(self, model, layers, with_grad, fp32_only=()):
+    def __init__(self, model, layers, with_grad, fp32_only=(), transposed=()):
+        """transposed: layers that also keep a bf16 copy [K][pad8(N)] behind the row-major shadows (the fused
+        backward's B operand, csrc/mlp_fused.hip); the optimizer launch maintains it (AdamExtras.tinfo)."""
         self.model = model
         self.flat = model.flatten_(with_grad=with_grad)
         dev = self.flat.device
@@ -124,7 +153,11 @@ class MlpWeights(object):
             shapes[name] = (n, k, _pad8(k))
             if name not in fp32_only:
                 total += n * _pad8(k)
-        self.shadow = torch.zeros(max(total, 8), dtype=BF16, device=dev)
+        self.transposed = tuple(transposed)
+        t_total = sum(shapes[name][1] * _pad8(shapes[name][0]) for name in self.transposed)
+        self.shadow = torch.zeros(max(total + t_total, 8), dtype=BF16, device=dev)
+        self.wT = {}
+        toff = total
         self.w, self.b, self.w32, self.off, self.shape = {}, {}, {}, {}, shapes
         entries, soff = [], 0
         covered = 0
@@ -145,10 +178,21 @@ class MlpWeights(object):
             covered += n * k + n
         assert covered == self.flat.numel(), "layer list does not cover the model's parameters"
         self.table = SegmentTable(entries, dev)
+        tinfo = torch.zeros(len(entries), 2, dtype=torch.int32)
+        for name in self.transposed:
+            n, k, _ = shapes[name]
+            npad = _pad8(n)
+            self.wT[name] = self.shadow[toff:toff + k * npad].view(k, npad)
+            tinfo[2 * self.layers.index(name)] = torch.tensor([toff, npad], dtype=torch.int32)
+            toff += k * npad
+        self.tinfo = tinfo.to(dev) if self.transposed else None
         self.refresh()
 
     def refresh(self):
         polyak_(self.flat, self.flat, 1.0, self.table, self.shadow)
+        for name in self.transposed:
+            n = self.shape[name][0]
+            self.wT[name][:, :n].copy_(self.w32[name].t())
 
     def grad_views(self, flat_grads):
         gw, gb = {}, {}
@@ -233,7 +277,8 @@ class DdpgMlpEngine(_EngineBase):
     def __init__(self, model, target_model, batch_size, lr=1e-4, weight_decay=0.0, clip=40.0, tau=1e-3,
                  per=None, seed=0, tail_offsets=(0, 1, 2, 3), leak=True, actor_warmup=0):
         self.actor_warmup = int(actor_warmup)
-        self.online = MlpWeights(model, DDPG_LAYERS, with_grad=True, fp32_only=("critic.1.2",))
+        self.online = MlpWeights(model, DDPG_LAYERS, with_grad=True, fp32_only=("critic.1.2",),
+                                 transposed=("critic.1.0", "actor.2"))
         self.target = MlpWeights(target_model, DDPG_LAYERS, with_grad=False, fp32_only=("critic.1.2",))
         on = self.online
         dev = on.flat.device
@@ -269,6 +314,86 @@ class DdpgMlpEngine(_EngineBase):
         self.adam = FlatAdam(on.flat, self.grads, on.table, lr=lr, weight_decay=weight_decay, clip=clip,
                              shadow=on.shadow)
         polyak_(self.target.flat, on.flat, 1.0, self.target.table, self.target.shadow)
+        # one launch for forward + head + data gradients, one for all weight gradients, one for Adam + Polyak +
+        # the next index draw (csrc/mlp_fused.hip); PDA_MLP_FUSED=0 keeps the layer-by-layer launches
+        self.fused = (os.environ.get("PDA_MLP_FUSED", "1") != "0"
+                      and bool(_L().pda_ddpg_fused_supported(self.D, self.H1, self.H2, self.A, self.C1, self.C2)))
+        self._wgrad_jobs = None
+
+    # ---- fused step (3 launches with uniform sampling) --------------------------------------------
+    def _layer(self, w, name):
+        n, k, kp = w.shape[name]
+        return _Layer(_p(w.w[name]), _p(w.b[name]), n, k, kp)
+
+    def fused_forward_backward(self, staged=False):
+        B, on, tg = self.B, self.online, self.target
+        s0, s1, tails, idx, tree = self._sources(staged)
+        oa, orw, og, ot = self.tail_offsets
+        a = _DdpgFusedArgs()
+        a.s0, a.s1, a.ld_s = _p(s0), _p(s1), int(s0.stride(0))
+        a.tails, a.tail_ld = _p(tails), int(tails.stride(0))
+        a.off_action, a.off_reward, a.off_gamma, a.off_term = oa, orw, og, ot
+        a.idx, a.isw = _p(idx), (_p(self.isw) if self.per is not None else 0)
+        for i, w in enumerate((on, tg)):
+            a.a0[i], a.a2[i], a.a4[i] = self._layer(w, "actor.0"), self._layer(w, "actor.2"), self._layer(w, "actor.4")
+            a.c0[i], a.c1[i] = self._layer(w, "critic.0.0"), self._layer(w, "critic.1.0")
+            a.w3[i], a.b3[i] = _p(w.w32["critic.1.2"]), _p(w.b["critic.1.2"])
+        a.c1T = _Layer(_p(on.wT["critic.1.0"]), 0, self.CK, self.C2, _pad8(self.C2))
+        a.a2T = _Layer(_p(on.wT["actor.2"]), 0, self.H1, self.H2, _pad8(self.H2))
+        a.x0, a.ld_x0 = _p(self.x0), self.Dp
+        a.ha1, a.ld_ha1 = _p(self.ha1[0]), self.ha1[0].shape[1]
+        a.ha2, a.ld_ha2 = _p(self.ha2[0]), self.ha2[0].shape[1]
+        a.cat, a.ld_cat = _p(self.cat_on), self.CKp
+        a.h2, a.ld_h2 = _p(self.h2), self.h2.shape[1]
+        a.dh2, a.dq, a.dq_ld = _p(self.dh2), _p(self.dq), 8
+        a.dcat, a.dha2, a.dha1 = _p(self.dcat), _p(self.dha2), _p(self.dha1)
+        a.q_out, a.td_out, a.loss_sum = _p(self.q), _p(self.td), _p(self.loss_acc)
+        a.leaf_sum = _p(tree.sum) if tree is not None else 0
+        a.leaf_min = _p(tree.min) if tree is not None else 0
+        a.prio_eps = float(self.per["eps"]) if self.per else 0.0
+        a.prio_alpha = float(self.per["alpha"]) if self.per else 1.0
+        a.B, a.D, a.A, a.C1 = B, self.D, self.A, self.C1
+        a.leak, a.actor_warmup = (1 if self.leak else 0), self.actor_warmup
+        a.rng_counter, a.opt_step = _p(self.counter), _p(self.adam.step_dev)
+        a.prof = _p(getattr(self, "prof", None))
+        _L().pda_ddpg_fused(ctypes.byref(a), _stream())
+
+    def wgrad_all(self):
+        """The six weight (+ bias) gradients as problem groups of ONE GEMM launch."""
+        if self._wgrad_jobs is None:
+            B = self.B
+            H1p, H2p, C2p, CKp = self.ha1[0].shape[1], self.ha2[0].shape[1], self.h2.shape[1], self.CKp
+            r0, rows = (0, 2 * B) if self.leak else (B, B)      # critic: both passes (reference) or the critic loss only
+            dz3 = self.dcat[:B, self.C1:]
+            jobs = [  # dy, x, layer, rows, N, K, lddy, ldx
+                (self.dq[r0:], self.h2[r0:], "critic.1.2", rows, 1, self.C2, 8, C2p),
+                (self.dh2[r0:], self.cat_on[r0:], "critic.1.0", rows, self.C2, self.CK, C2p, CKp),
+                (self.dcat[r0:], self.x0[r0:], "critic.0.0", rows, self.C1, self.D, CKp, self.Dp),
+                (dz3, self.ha2[0], "actor.4", B, self.A, self.H2, CKp, H2p),
+                (self.dha2, self.ha1[0], "actor.2", B, self.H2, self.H1, H2p, H1p),
+                (self.dha1, self.x0, "actor.0", B, self.H1, self.D, H1p, self.Dp)]
+            n = len(jobs)
+            vp, ci, cl = _vp * n, ctypes.c_int * n, ctypes.c_long * n
+            self._wgrad_jobs = (n, vp(*[_p(j[0]) for j in jobs]), vp(*[_p(j[1]) for j in jobs]),
+                                vp(*[_p(self.gw[j[2]]) for j in jobs]), vp(*[_p(self.gb[j[2]]) for j in jobs]),
+                                ci(*[j[3] for j in jobs]), ci(*[j[4] for j in jobs]), ci(*[j[5] for j in jobs]),
+                                cl(*[j[6] for j in jobs]), cl(*[j[7] for j in jobs]), cl(*[j[5] for j in jobs]))
+        _L().pda_linear_wgrad_n(*self._wgrad_jobs, _stream())
+
+    def fused_extras(self, staged):
+        """Transposed shadows, the Polyak update of the target network and (uniform sampling from device replay)
+        the next step's index draw, all inside the optimizer launch."""
+        from .optim import AdamExtras
+        x = AdamExtras()
+        x.tinfo = _p(self.online.tinfo)
+        x.tgt, x.tgt_shadow, x.tau = _p(self.target.flat), _p(self.target.shadow), float(self.tau)
+        if self.presamples(staged):
+            x.next_idx, x.next_w, x.next_B = _p(self.idx), _p(self.isw), self.B
+            x.size, x.seed, x.counter = _p(self.size_dev), self.seed, _p(self.counter)
+        return x
+
+    def presamples(self, staged):
+        return (not staged) and self.replay is not None and not (self.replay[3] is not None and self.per is not None)
 
     # ---- step pieces ---------------------------------------------------------------------------
     def forward_head(self, staged=False):
@@ -340,10 +465,20 @@ class DdpgMlpEngine(_EngineBase):
                         act=nn.ACT_TANH)
         nn.linear_wgrad(self.dha1, self.x0, gw["actor.0"], gb["actor.0"], B, self.H1, self.D, H1p, self.Dp, self.D)
 
-    def update(self, staged=False, tick=False):
-        self.adam.step(tick=tick)
-        polyak_(self.target.flat, self.online.flat, self.tau, self.target.table, self.target.shadow)
+    def update(self, staged=False, tick=False, extras=None):
+        if extras is not None:          # Polyak (and the transposed shadows) ride in the optimizer launch
+            self.adam.step(tick=tick, extras=extras)
+        else:
+            self.adam.step(tick=tick, extras=self._tinfo_extras())
+            polyak_(self.target.flat, self.online.flat, self.tau, self.target.table, self.target.shadow)
         self._finish_update(staged)
+
+    def _tinfo_extras(self):
+        if getattr(self, "_tx", None) is None:
+            from .optim import AdamExtras
+            self._tx = AdamExtras()
+            self._tx.tinfo = _p(self.online.tinfo)
+        return self._tx
 
     def hard_target_update(self):
         polyak_(self.target.flat, self.online.flat, 1.0, self.target.table, self.target.shadow)
@@ -470,15 +605,27 @@ class MlpStepProgram(object):
         self.graph_steps, self.ahead = max(1, k), 0
         if self.dp:     # the all-reduce is a SUM; Adam applies the 1/world_size
             engine.adam.set_grad_scale(1.0 / self.world)
+        self.fused = bool(getattr(engine, "fused", False))
+        self.extras = engine.fused_extras(staged) if self.fused else None
+        self.presampled = False
 
     def _part_a(self):
-        if not self.staged:
-            self.e.sample()
-        self.e.forward_head(self.staged)
-        self.e.backward(self.staged)
+        e = self.e
+        if not self.staged and not (self.fused and self.presampled and e.presamples(self.staged)):
+            e.sample()
+        if self.fused:
+            e.fused_forward_backward(self.staged)
+            e.wgrad_all()
+        else:
+            e.forward_head(self.staged)
+            e.backward(self.staged)
 
     def _part_c(self):
-        self.e.update(self.staged)
+        if self.fused:
+            self.e.update(self.staged, extras=self.extras)
+            self.presampled = True
+        else:
+            self.e.update(self.staged)
 
     def _all(self):
         self._part_a()

@@ -71,10 +71,12 @@ def ddpg_reference(model, target, s0, s1, tails, A, leak, isw=None):
     return q_pi.detach().reshape(-1), (pred - y).detach().reshape(-1), actor_loss.item(), critic_loss.item()
 
 
-@pytest.mark.parametrize("B,D,A,leak", [(64, 3, 1, True), (64, 3, 1, False), (128, 17, 6, True)])
-def test_ddpg_forward_backward_matches_torch(eng, B, D, A, leak):
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("B,D,A,leak", [(64, 3, 1, True), (64, 3, 1, False), (128, 17, 6, True), (40, 5, 2, False)])
+def test_ddpg_forward_backward_matches_torch(eng, B, D, A, leak, fused):
     model, target = make_ddpg(D, A)
     e = eng.DdpgMlpEngine(model, target, B, leak=leak, tail_offsets=(0, A, A + 1, A + 2))
+    assert e.fused, "the fused DDPG kernel must support the reference's layer sizes"
     with torch.no_grad():
         for p in target.parameters():
             p.add_(0.02 * torch.randn_like(p))
@@ -83,8 +85,12 @@ def test_ddpg_forward_backward_matches_torch(eng, B, D, A, leak):
     s0, s1, tails = ddpg_batch(B, D, A)
     e.make_staging(A + 4)
     e.stage_s0.copy_(s0); e.stage_s1.copy_(s1); e.stage_tails.copy_(tails)
-    e.forward_head(staged=True)
-    e.backward(staged=True)
+    if fused:       # one launch for forward + head + data gradients, one for the six weight gradients
+        e.fused_forward_backward(staged=True)
+        e.wgrad_all()
+    else:
+        e.forward_head(staged=True)
+        e.backward(staged=True)
     torch.cuda.synchronize()
     q_pi, td, al, cl = ddpg_reference(ref, tref, s0, s1, tails, A, leak)
     assert rel_err(e.q[:B], q_pi) < 3e-2
@@ -99,6 +105,73 @@ def test_ddpg_forward_backward_matches_torch(eng, B, D, A, leak):
     print("ddpg grad rel errs:", {k: round(v, 4) for k, v in errs.items()})
     for name, err in errs.items():
         assert err < 6e-2, "%s: rel err %g (all: %s)" % (name, err, errs)
+
+
+def test_ddpg_fused_kernel_equals_the_layer_by_layer_launches(eng):
+    """Same bf16 operands, same fp32 accumulation order per 32-wide k-step: the fused launch must reproduce the
+    unfused buffers (activations, data gradients, flat parameter gradient) to rounding of the last bf16 bit."""
+    B, D, A = 64, 3, 1
+    s0, s1, tails = ddpg_batch(B, D, A)
+    outs = []
+    for fused in (False, True):
+        model, target = make_ddpg(D, A, seed=3)
+        e = eng.DdpgMlpEngine(model, target, B, leak=True, tail_offsets=(0, A, A + 1, A + 2))
+        e.make_staging(A + 4)
+        e.stage_s0.copy_(s0); e.stage_s1.copy_(s1); e.stage_tails.copy_(tails)
+        if fused:
+            e.fused_forward_backward(staged=True)
+            e.wgrad_all()
+        else:
+            e.forward_head(staged=True)
+            e.backward(staged=True)
+        torch.cuda.synchronize()
+        outs.append({"q": e.q.clone(), "td": e.td.clone(), "h2": e.h2[:2 * B].float(), "cat": e.cat_on.float(),
+                     "dh2": e.dh2.float(), "dcat": e.dcat.float(), "dha2": e.dha2.float(), "dha1": e.dha1.float(),
+                     "grads": e.grads.clone()})
+    a, b = outs
+    for k in a:
+        err = rel_err(b[k], a[k])
+        print("fused vs unfused %-6s rel err %.2e" % (k, err))
+        assert err < 2e-3, (k, err)
+
+
+def test_ddpg_fused_step_is_three_launches_and_keeps_the_transposed_shadows(eng):
+    """Uniform sampling from device replay: fused forward/backward, grouped weight gradients, optimizer (+ Polyak +
+    transposed shadows + next index draw).  After a few steps the transposed copies equal the masters' transposes
+    and the target follows by Polyak."""
+    B, D, A, n = 64, 3, 1, 512
+    model, target = make_ddpg(D, A, seed=5)
+    e = eng.DdpgMlpEngine(model, target, B, lr=1e-3, tau=0.01, leak=False, tail_offsets=(0, A, A + 1, A + 2), seed=9)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    s0 = torch.randn(n, D, device="cuda", generator=g)
+    s1 = torch.randn(n, D, device="cuda", generator=g)
+    tails = torch.zeros(n, A + 4, device="cuda")
+    tails[:, :A] = torch.rand(n, A, device="cuda", generator=g) * 2 - 1
+    tails[:, A] = torch.randn(n, device="cuda", generator=g)
+    tails[:, A + 1] = 0.99
+    e.bind_replay(s0, s1, tails, None)
+    e.set_size(n)
+    tgt0 = e.target.flat.clone()
+    prog = eng.MlpStepProgram(e, None, use_graph=True, staged=False, graph_steps=1)
+    assert prog.fused and prog.extras is not None
+    seen = []
+    for _ in range(6):
+        prog.step()
+        torch.cuda.synchronize()
+        seen.append(e.idx.clone())
+    assert prog.graphs is not None and prog.presampled
+    assert all(0 <= int(i.min()) and int(i.max()) < n for i in seen)
+    assert not torch.equal(seen[-1], seen[-2])          # a fresh draw per step, made by the optimizer launch
+    for name in ("critic.1.0", "actor.2"):
+        w = dict(model.named_parameters())[name + ".weight"].detach()
+        nn_, kk = w.shape
+        assert torch.equal(e.online.wT[name][:, :nn_], w.t().to(torch.bfloat16)), name
+        assert torch.equal(e.online.w[name][:, :kk], w.to(torch.bfloat16)), name
+    assert (e.target.flat - tgt0).abs().max().item() > 0
+    assert torch.equal(e.target.w["critic.1.0"][:, :e.CK],
+                       target.critic[1][0].weight.detach().to(torch.bfloat16))
+    import ctypes
+    assert ctypes.sizeof(eng._DdpgFusedArgs) < 4096
 
 
 def test_ddpg_steps_track_torch_core(eng):
