@@ -135,8 +135,17 @@ class DdpgTorchCore(_TorchCore):
         if not leak:
             for p in self.model.critic.parameters():
                 p.requires_grad_(False)
-        _, q_pi = self.model(s0)
-        actor_loss = -q_pi.mean()
+        lam = float(getattr(self.ap, "actor_preact_l2", 0.0) or 0.0)
+        if lam > 0:
+            # + lam * mean(z^2) on the actor's pre-tanh output z: once a tanh policy saturates, d(-Q)/dz = dQ/da (1 - a^2)
+            # is ~0 and it can never come back; this term's gradient does not pass through tanh' (options.py, preset 7)
+            z = self.model.actor[:-1](s0.float().flatten(1))
+            action = torch.tanh(z)
+            q_pi = self.model.forward_critic(s0, action)
+            actor_loss = -q_pi.mean() + lam * (z ** 2).sum(dim=1).mean()
+        else:
+            _, q_pi = self.model(s0)
+            actor_loss = -q_pi.mean()
         self._ddpg_updates = getattr(self, "_ddpg_updates", 0) + 1
         if self._ddpg_updates >= int(getattr(self.ap, "actor_warmup_steps", 0)):    # critic warm-up: see options
             actor_loss.backward()

@@ -68,6 +68,7 @@ struct DdpgFusedArgs {
     float* q_out; float* td_out; float* loss_sum; float* leaf_sum; float* leaf_min; float prio_eps, prio_alpha;
     int B, D, A, C1, leak, actor_warmup;
     unsigned long long* rng_counter; int* opt_step;
+    float actor_l2;         // + actor_l2 * mean_b |z_b|^2 in the actor loss, z = the actor's pre-tanh output (0: off)
     long long* prof;        // optional: wall_clock64() of workgroup 0 at every phase boundary (tools/bench_mlp_step.py --phases)
 };
 
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void ddpg_fused_kernel(DdpgFusedArgs
     float* W3 = BIAS + 2 * SB;              // [2][C2] critic output weights, online | target
     float* TL = W3 + 2 * C2;                // [16][4] reward, gamma^n, done, importance weight of the tile's rows
     float* A4W = TL + 16 * 4;               // [A][H2] online actor output weights (from the bf16 shadow)
+    float* ZA = A4W + A * H2;               // [16][8] the online actor's pre-tanh output (actor_l2 penalty)
     const int oA0 = 0, oA2 = H1, oA4 = H1 + H2, oC0 = H1 + H2 + A, oC1 = H1 + H2 + A + C1;
 
     // ---- zero LDS (pad columns multiply zero weights, but must be finite), then stage the replay rows ----
@@ -278,7 +280,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void ddpg_fused_kernel(DdpgFusedArgs
             if (n >= L.N) return;
             const float bias = BIAS[grp * SB + oA4 + n];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) out[(row + i) * pc + C1 + n] = f2bf(fast_tanh(acc[0][i] + bias));
+            for (int i = 0; i < 4; ++i) {
+                out[(row + i) * pc + C1 + n] = f2bf(fast_tanh(acc[0][i] + bias));
+                if (!grp && n < 8) ZA[(row + i) * 8 + n] = acc[0][i] + bias;
+            }
         });
     }
     {
@@ -354,7 +359,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void ddpg_fused_kernel(DdpgFusedArgs
             if (lane == 0) {
                 if (p.q_out) { p.q_out[b] = q_pi; p.q_out[B + b] = q_c; p.q_out[2 * B + b] = q_t; }
                 if (p.td_out) p.td_out[b] = td;
-                atomicAdd(p.loss_sum, -q_pi * invB);
+                float pen = 0.f;
+                if (p.actor_l2 > 0.f)
+                    for (int a = 0; a < A; ++a) pen += ZA[r * 8 + a] * ZA[r * 8 + a];
+                atomicAdd(p.loss_sum, (-q_pi + p.actor_l2 * pen) * invB);
                 atomicAdd(p.loss_sum + 1, w * td * td * invB);
                 if (p.leaf_sum) {
                     const long row = p.idx ? (long)p.idx[b] : (long)b;
@@ -389,8 +397,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void ddpg_fused_kernel(DdpgFusedArgs
             for (int i = 0; i < 4; ++i) {
                 const int r = row + i;
                 const float yp = bf2f(CATP[r * pc + n]), yc = bf2f(CATC[r * pc + n]);
-                const float gp = acc[0][i] * (1.f - yp * yp), gc = acc[1][i] * (1.f - yc * yc);
-                if (n >= C1 && n - C1 < 8) dz3[r * 8 + (n - C1)] = gp;
+                float gp = acc[0][i] * (1.f - yp * yp);
+                const float gc = acc[1][i] * (1.f - yc * yc);
+                if (n >= C1 && n - C1 < 8) {
+                    // the penalty's gradient does not pass through tanh': it is what brings a saturated actor back
+                    if (actor_on && r0 + r < B) gp += 2.f * p.actor_l2 * invB * ZA[r * 8 + (n - C1)];
+                    dz3[r * 8 + (n - C1)] = gp;
+                }
                 DCATP[r * pc + n] = f2bf(gp);
                 DCATC[r * pc + n] = f2bf(gc);
             }
@@ -461,7 +474,7 @@ PDA_EXPORT int pda_ddpg_fused_supported(int D, int H1, int H2, int A, int C1, in
     if (!(D <= lim && H1 <= lim && H2 <= lim && C1 + A <= lim && C2 <= lim && A <= 8 && C1 % 8 == 0)) return 0;
     const int pD = lds_pitch(D), p1 = lds_pitch(H1), p2 = lds_pitch(H2), pc = lds_pitch(C1 + A), ph = lds_pitch(C2);
     const long bytes = 16L * 2 * (2 * pD + 2 * p1 + 2 * p2 + 4 * pc + 4 * ph) + 16 * 8 * 4 + 16 * 4 * 4 +
-                       2L * 4 * (H1 + H2 + A + C1 + C2) + 4L * (2 * C2 + 16 * 4 + A * H2);
+                       2L * 4 * (H1 + H2 + A + C1 + C2) + 4L * (2 * C2 + 16 * 4 + A * H2 + 16 * 8);
     return bytes <= 160 * 1024;
 }
 
@@ -470,7 +483,7 @@ PDA_EXPORT void pda_ddpg_fused(const DdpgFusedArgs* args, hipStream_t stream) {
     const int H1 = p.a0[0].N, H2 = p.a2[0].N, C2 = p.c1[0].N;
     const int pD = lds_pitch(p.D), p1 = lds_pitch(H1), p2 = lds_pitch(H2), pc = lds_pitch(p.C1 + p.A), ph = lds_pitch(C2);
     const size_t lds = 16u * 2 * (2 * pD + 2 * p1 + 2 * p2 + 4 * pc + 4 * ph) + 16 * 8 * 4 + 16 * 4 * 4 +
-                       2u * 4 * (H1 + H2 + p.A + p.C1 + C2) + 4u * (2 * C2 + 16 * 4 + p.A * H2);
+                       2u * 4 * (H1 + H2 + p.A + p.C1 + C2) + 4u * (2 * C2 + 16 * 4 + p.A * H2 + 16 * 8);
     static size_t granted = 0;
     if (lds > granted) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ddpg_fused_kernel),

@@ -95,7 +95,7 @@ class _DdpgFusedArgs(ctypes.Structure):     # mirrors DdpgFusedArgs in csrc/mlp_
                 ("prio_eps", ctypes.c_float), ("prio_alpha", ctypes.c_float),
                 ("B", ctypes.c_int), ("D", ctypes.c_int), ("A", ctypes.c_int), ("C1", ctypes.c_int),
                 ("leak", ctypes.c_int), ("actor_warmup", ctypes.c_int), ("rng_counter", _vp), ("opt_step", _vp),
-                ("prof", _vp)]
+                ("actor_l2", ctypes.c_float), ("prof", _vp)]
 
 
 _ready = False
@@ -275,8 +275,9 @@ DDPG_LAYERS = ("actor.0", "actor.2", "actor.4", "critic.0.0", "critic.1.0", "cri
 
 class DdpgMlpEngine(_EngineBase):
     def __init__(self, model, target_model, batch_size, lr=1e-4, weight_decay=0.0, clip=40.0, tau=1e-3,
-                 per=None, seed=0, tail_offsets=(0, 1, 2, 3), leak=True, actor_warmup=0):
+                 per=None, seed=0, tail_offsets=(0, 1, 2, 3), leak=True, actor_warmup=0, actor_l2=0.0):
         self.actor_warmup = int(actor_warmup)
+        self.actor_l2 = float(actor_l2)
         self.online = MlpWeights(model, DDPG_LAYERS, with_grad=True, fp32_only=("critic.1.2",),
                                  transposed=("critic.1.0", "actor.2"))
         self.target = MlpWeights(target_model, DDPG_LAYERS, with_grad=False, fp32_only=("critic.1.2",))
@@ -319,6 +320,8 @@ class DdpgMlpEngine(_EngineBase):
         self.fused = (os.environ.get("PDA_MLP_FUSED", "1") != "0"
                       and bool(_L().pda_ddpg_fused_supported(self.D, self.H1, self.H2, self.A, self.C1, self.C2)))
         self._wgrad_jobs = None
+        if self.actor_l2 > 0 and not self.fused:
+            raise ValueError("actor_preact_l2 is implemented by the fused DDPG kernel only (PDA_MLP_FUSED=0 / shape)")
 
     # ---- fused step (3 launches with uniform sampling) --------------------------------------------
     def _layer(self, w, name):
@@ -355,6 +358,7 @@ class DdpgMlpEngine(_EngineBase):
         a.B, a.D, a.A, a.C1 = B, self.D, self.A, self.C1
         a.leak, a.actor_warmup = (1 if self.leak else 0), self.actor_warmup
         a.rng_counter, a.opt_step = _p(self.counter), _p(self.adam.step_dev)
+        a.actor_l2 = self.actor_l2
         a.prof = _p(getattr(self, "prof", None))
         _L().pda_ddpg_fused(ctypes.byref(a), _stream())
 
@@ -694,7 +698,8 @@ class MlpNativeCore(object):
             self.engine = DdpgMlpEngine(model, target_model, ap.batch_size, lr=ap.lr, weight_decay=ap.weight_decay,
                                         clip=ap.clip_grad, tau=ap.target_model_update, per=per, seed=seed,
                                         tail_offsets=offs, leak=getattr(ap, "compat_ddpg_grad_leak", True),
-                                        actor_warmup=getattr(ap, "actor_warmup_steps", 0))
+                                        actor_warmup=getattr(ap, "actor_warmup_steps", 0),
+                                        actor_l2=float(getattr(ap, "actor_preact_l2", 0.0) or 0.0))
             assert self.engine.A == a
         else:
             self.engine = DqnMlpEngine(model, target_model, ap.batch_size, lr=ap.lr, weight_decay=ap.weight_decay,

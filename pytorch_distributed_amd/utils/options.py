@@ -62,11 +62,17 @@ PRESETS = {
     #   actor_sync_freq 50 (ref. 400)  per actor: with 8 actors 400 steps are 3 200 updates of policy lag (1 of 2 seeds)
     #   ou_stationary_start            N actors starting their OU noise at 0 fill the first learn_start transitions
     #                                  with |a| << 1 (3 of 4 seeds without, 4 of 4 with)
+    #   actor_preact_l2 0.01           + 0.01 mean |z|^2 on the actor's pre-tanh output z.  Everything above makes
+    #                                  learning LIKELY (3 of 4 .. 4 of 4 seeds on the slow CPU job, 1 of 4 .. 2 of 5 with
+    #                                  the 12 k updates/s native learner): a tanh actor that the first, meaningless
+    #                                  critic gradients push into saturation has dQ/da (1 - a^2) ~ 0 and never comes
+    #                                  back.  The penalty's gradient does not pass through tanh': 8 of 8 seeds.
     # Not needed (measured): reward scaling, separate actor/critic rates, a larger tau, critic-only warm-up (hurts).
     7: {"num_actors": 8, "agent_params.nstep": 1, "agent_params.lr": 1e-3,
         "agent_params.compat_ddpg_grad_leak": False, "agent_params.max_replay_ratio": 1.0,
         "agent_params.min_replay_ratio": 1.0, "agent_params.actor_sync_freq": 50,
-        "agent_params.ou_stationary_start": True, "memory_params.memory_size": 1024 * 1024},
+        "agent_params.ou_stationary_start": True, "agent_params.actor_preact_l2": 0.01,
+        "memory_params.memory_size": 1024 * 1024},
 }
 
 
@@ -281,6 +287,7 @@ class AgentParams(Params):
             # (ddpg_learner.py:66-86); False freezes the critic during the actor loss
             self.compat_ddpg_grad_leak = True
             self.ou_stationary_start = False # DDPG actors: OU noise starts at its stationary spread, not at 0 (see agents/actors.py)
+            self.actor_preact_l2 = 0.0       # DDPG: + this * mean(|pre-tanh actor output|^2) in the actor loss (0: as the reference)
             self.actor_warmup_steps = 0      # DDPG: learner updates during which only the critic is trained (0: as the reference)
 
 

@@ -275,6 +275,38 @@ def test_ddpg_actor_warmup_trains_only_the_critic():
     assert (actor0 - actor2).abs().max().item() > 0
 
 
+def test_ddpg_actor_preact_penalty_pulls_a_saturated_actor_back():
+    """agent_params.actor_preact_l2: with the actor's output layer blown up so that tanh saturates (|a| = 1 in fp32,
+    d(-Q)/dz = 0), the plain actor loss leaves the actor where it is; with the penalty it moves, towards smaller |z|."""
+    B = 8
+    moved = {}
+    for lam in (0.0, 0.01):
+        opt = prepare_options(Options(config=3, overrides={"device": "cpu", "agent_params.batch_size": B,
+                                                           "agent_params.lr": 1e-3, "agent_params.actor_preact_l2": lam,
+                                                           "agent_params.compat_ddpg_grad_leak": False}))
+        D, A = int(np.prod(opt.state_shape)), int(opt.action_shape)
+        g = torch.Generator().manual_seed(5)
+        full = [(torch.randn(B, 1, D, generator=g), torch.rand(B, A, generator=g) * 2 - 1,
+                 torch.randn(B, 1, generator=g), torch.full((B, 1), 0.95), torch.randn(B, 1, D, generator=g),
+                 torch.zeros(B, 1))]
+        torch.manual_seed(1)
+        proto = ModelsDict[opt.model_type](opt.model_params, opt.norm_val, opt.state_shape, opt.action_space,
+                                           opt.action_shape)
+        with torch.no_grad():
+            proto.actor[4].bias.fill_(40.0)             # z ~ 40: tanh(z) == 1.0 exactly in fp32
+        core = DdpgTorchCore(opt, copy.deepcopy(proto), copy.deepcopy(proto), FixedBatchMemory(full), SingleComm())
+        z0 = core.model.actor[:-1](full[0][0].flatten(1)).detach()
+        assert torch.tanh(z0).abs().min().item() == 1.0
+        a0 = torch.cat([p.detach().reshape(-1).clone() for p in core.model.actor.parameters()])
+        for _ in range(3):
+            core.step()
+        a1 = torch.cat([p.detach().reshape(-1) for p in core.model.actor.parameters()])
+        z1 = core.model.actor[:-1](full[0][0].flatten(1)).detach()
+        moved[lam] = ((a1 - a0).abs().max().item(), (z0.abs().mean() - z1.abs().mean()).item())
+    assert moved[0.0][0] == 0.0                           # stuck for good without it
+    assert moved[0.01][0] > 0 and moved[0.01][1] > 0      # |z| shrinks with it
+
+
 def _weight_sync_worker(rank, port, out_q):
     """2 learner ranks + 1 inference rank in one gloo world: sub-group collectives + weight broadcast."""
     from pytorch_distributed_amd.parallel.weight_sync import WeightPublisher, WeightReceiver

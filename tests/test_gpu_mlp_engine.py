@@ -49,15 +49,16 @@ def ddpg_batch(B, D, A, seed=1):
     return s0, s1, tails
 
 
-def ddpg_reference(model, target, s0, s1, tails, A, leak, isw=None):
+def ddpg_reference(model, target, s0, s1, tails, A, leak, isw=None, actor_l2=0.0):
     """The reference's two backward passes (ddpg_learner.py:66-86)."""
     model.zero_grad(set_to_none=True)
     a, r, g, t = tails[:, :A], tails[:, A:A + 1], tails[:, A + 1:A + 2], tails[:, A + 2:A + 3]
     if not leak:
         for p in model.critic.parameters():
             p.requires_grad_(False)
-    _, q_pi = model(s0)
-    actor_loss = -q_pi.mean()
+    z = model.actor[:-1](s0.flatten(1))
+    q_pi = model.forward_critic(s0, torch.tanh(z))
+    actor_loss = -q_pi.mean() + actor_l2 * (z ** 2).sum(1).mean()
     actor_loss.backward()
     for p in model.critic.parameters():
         p.requires_grad_(True)
@@ -133,6 +134,28 @@ def test_ddpg_fused_kernel_equals_the_layer_by_layer_launches(eng):
         err = rel_err(b[k], a[k])
         print("fused vs unfused %-6s rel err %.2e" % (k, err))
         assert err < 2e-3, (k, err)
+
+
+def test_ddpg_actor_preact_penalty_matches_torch(eng):
+    """actor_l2 * mean |z|^2 on the pre-tanh actor output (what keeps the tanh policy out of saturation for good)."""
+    B, D, A, lam = 64, 3, 2, 0.5
+    model, target = make_ddpg(D, A, seed=7)
+    e = eng.DdpgMlpEngine(model, target, B, leak=False, tail_offsets=(0, A, A + 1, A + 2), actor_l2=lam)
+    ref, tref = copy.deepcopy(model), copy.deepcopy(target)
+    s0, s1, tails = ddpg_batch(B, D, A)
+    e.make_staging(A + 4)
+    e.stage_s0.copy_(s0); e.stage_s1.copy_(s1); e.stage_tails.copy_(tails)
+    e.fused_forward_backward(staged=True)
+    e.wgrad_all()
+    torch.cuda.synchronize()
+    _, _, al, _ = ddpg_reference(ref, tref, s0, s1, tails, A, False, actor_l2=lam)
+    assert abs(e.loss_acc[0].item() - al) < 3e-2 * max(1.0, abs(al))
+    off = 0
+    for name, p in ref.named_parameters():
+        got = e.grads[off:off + p.numel()].view_as(p)
+        off += p.numel()
+        if name.startswith("actor"):
+            assert rel_err(got, p.grad) < 3e-2, (name, rel_err(got, p.grad))
 
 
 def test_ddpg_fused_step_is_three_launches_and_keeps_the_transposed_shadows(eng):
