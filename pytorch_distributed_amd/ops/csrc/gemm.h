@@ -262,6 +262,25 @@ struct SrcSplit {
 #define SPLIT_X2(S) SrcSplit<S, 2, 0>      /* exact operand, twice */
 #define SPLIT_HL2(S) SrcSplit<S, 2, 2>     /* (hi, lo) against an exact operand */
 
+// One plane of a split operand as a plain source (the x3 body below stages hi and lo tiles side by side).
+template <class S>
+struct SrcPlane {
+    static constexpr bool kT = S::kT;
+    S s; long off;
+    typedef typename S::Ctx Ctx;
+    typedef typename S::Raw Raw;
+    __device__ __forceinline__ Ctx prep(int row) const { return s.prep(row); }
+    __device__ __forceinline__ static uint4 finish(Raw v, bool ok) { return S::finish(v, ok); }
+    __device__ __forceinline__ Raw raw(const Ctx& c, int k, int lim, bool& ok) const { return s.raw_at(c, k, lim, ok, off); }
+};
+template <class T> struct SplitTraits { static constexpr bool kSplit = false; static constexpr bool kHasLo = false; typedef T Base; };
+template <class S, int NT, int LOMASK>
+struct SplitTraits<SrcSplit<S, NT, LOMASK>> {
+    static constexpr bool kSplit = true;
+    static constexpr bool kHasLo = LOMASK != 0;     // X2 (exact operand, e.g. uint8 frames): one plane only
+    typedef S Base;
+};
+
 // hi / lo planes of an fp32 value (lo written `plane` elements after hi; plane == 0: plain bf16 output)
 __device__ __forceinline__ void store_split(bf16_t* dst, long plane, float x) {
     bf16_t h = f2bf(x);
@@ -510,14 +529,22 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16_t* lds, int r0, int ks, i
 
 template <int BM, int BN, int BK, class SA, class SB>
 constexpr int gemm_lds_elems() {
-    return 2 * (LdsShape<SA::kT, BM, BK>::kElems + LdsShape<SB::kT, BN, BK>::kElems);
+    return 2 * (LdsShape<SA::kT, BM, BK>::kElems * (SplitTraits<SA>::kHasLo ? 2 : 1) +
+                LdsShape<SB::kT, BN, BK>::kElems * (SplitTraits<SB>::kHasLo ? 2 : 1));
 }
+
+template <int BM, int BN, int WM, int WN, int BK, class SA, class SB, class EP>
+__device__ __forceinline__ void gemm_body_x3(const GemmArgs<SA, SB, EP>& args, int bx, int by, int bz, bf16_t* lds);
 
 // The work of one workgroup.  (bx, by, bz) = (tile, k-slice, problem group): blockIdx for a plain launch, a
 // decoded linear index when two GEMMs share one launch (gemm_duo_kernel).
 template <int BM, int BN, int WM, int WN, int BK, class SA, class SB, class EP>
 __device__ __forceinline__ void gemm_body(const GemmArgs<SA, SB, EP>& args, int bx, int by, int bz, bf16_t* lds) {
     static_assert(WM * WN == 4, "4 waves per block");
+    if constexpr (SplitTraits<SA>::kSplit || SplitTraits<SB>::kSplit) {
+        gemm_body_x3<BM, BN, WM, WN, BK, SA, SB, EP>(args, bx, by, bz, lds);
+        return;
+    } else {
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
     static_assert(FM >= 1 && FN >= 1, "tile too small for the wave grid");
     constexpr bool TA = SA::kT, TB = SB::kT;
@@ -604,6 +631,140 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<SA, SB, EP>& args, int 
     }
 
     // C/D layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
+    const EP ep = epi_for_slice(G.e, args.ksplit > 0 ? by : 0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        int m = m0 + wm * (BM / WM) + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            int n = n0 + wn * (BN / WN) + j * 16 + (lane & 15);
+            ep(m, n, acc[i][j], G.M, G.N);
+        }
+        if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ep.bias_grad(m + r, accb[i][r], G.M);
+        }
+    }
+    }   // !split
+}
+
+// The same workgroup program for split-bf16 operands (SrcSplit): fp32-equivalent products as
+//     a b ~= a_hi b_hi + a_lo b_hi + a_hi b_lo        (one operand exact in bf16: a b_hi + a b_lo)
+// with the hi and lo tiles of every k-tile staged ONCE, side by side in LDS, and the two or three MFMAs issued
+// per fragment pair.  (Round 2's first fp32-precision path ran the products as one reduction of three times the
+// length -- SrcSplit::raw, still used by nothing else -- which fetched and staged every hi tile twice and paid the
+// k-loop's barrier + commit three times per logical k-tile; at batch 128 those launches are bound by exactly that.)
+// GemmGroup::K, ksplit and the slice layout are in LOGICAL reduction units here.
+template <int BM, int BN, int WM, int WN, int BK, class SA, class SB, class EP>
+__device__ __forceinline__ void gemm_body_x3(const GemmArgs<SA, SB, EP>& args, int bx, int by, int bz, bf16_t* lds) {
+    constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+    static_assert(FM >= 1 && FN >= 1, "tile too small for the wave grid");
+    static_assert(SplitTraits<SA>::kSplit && SplitTraits<SB>::kSplit, "both operands are given as SrcSplit");
+    typedef typename SplitTraits<SA>::Base BA;
+    typedef typename SplitTraits<SB>::Base BB;
+    constexpr bool LA = SplitTraits<SA>::kHasLo, LB = SplitTraits<SB>::kHasLo;
+    static_assert(LA || LB, "at least one operand has a lo plane");
+    constexpr bool TA = BA::kT, TB = BB::kT;
+    constexpr int A_ELEMS = LdsShape<TA, BM, BK>::kElems, B_ELEMS = LdsShape<TB, BN, BK>::kElems;
+    constexpr int BUF = A_ELEMS * (LA ? 2 : 1) + B_ELEMS * (LB ? 2 : 1);
+
+    const GemmGroup<SA, SB, EP>& G = args.g[bz];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile_m = bx / args.tiles_n, tile_n = bx % args.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (m0 >= G.M || n0 >= G.N) return;
+    int kbeg = 0, kend = G.K;
+    if (args.ksplit > 0) {
+        kbeg = by * args.ksplit;
+        kend = min(G.K, kbeg + args.ksplit);
+        if (kbeg >= kend) return;
+    }
+    const SrcPlane<BA> ah = {G.a.s, 0}, al = {G.a.s, G.a.plane};
+    const SrcPlane<BB> bh = {G.b.s, 0}, bl = {G.b.s, G.b.plane};
+    Stager<TA, BM, BK, SrcPlane<BA>> sah, sal;
+    Stager<TB, BN, BK, SrcPlane<BB>> sbh, sbl;
+    sah.init(ah, m0, tid);
+    sbh.init(bh, n0, tid);
+    if (LA) sal.init(al, m0, tid);
+    if (LB) sbl.init(bl, n0, tid);
+
+    f32x4 acc[FM][FN];
+    f32x4 accb[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = EP::kBiasGrad && tile_n == 0 && wn == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    auto fetch_all = [&](auto slot_tag, int kk) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        sah.template fetch<SLOT>(ah, kk, kend);
+        sbh.template fetch<SLOT>(bh, kk, kend);
+        if (LA) sal.template fetch<SLOT>(al, kk, kend);
+        if (LB) sbl.template fetch<SLOT>(bl, kk, kend);
+    };
+    auto tile = [&](auto slot_tag, int kk, int& buf) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        bf16_t* lah = lds + buf * BUF;
+        bf16_t* lal = lah + A_ELEMS;
+        bf16_t* lbh = lah + A_ELEMS * (LA ? 2 : 1);
+        bf16_t* lbl = lbh + B_ELEMS;
+        sah.template commit<SLOT>(lah, tid);
+        sbh.template commit<SLOT>(lbh, tid);
+        if (LA) sal.template commit<SLOT>(lal, tid);
+        if (LB) sbl.template commit<SLOT>(lbl, tid);
+        __syncthreads();
+        fetch_all(slot_tag, kk + GEMM_PF * BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 fah[FM], fal[FM], fbh[FN], fbl[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                fah[i] = read_frag<TA, BM, BK>(lah, wm * (BM / WM) + i * 16, ks, lane);
+                if (LA) fal[i] = read_frag<TA, BM, BK>(lal, wm * (BM / WM) + i * 16, ks, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                fbh[j] = read_frag<TB, BN, BK>(lbh, wn * (BN / WN) + j * 16, ks, lane);
+                if (LB) fbl[j] = read_frag<TB, BN, BK>(lbl, wn * (BN / WN) + j * 16, ks, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+                    if (LA) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
+                    if (LB) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
+                }
+                if (do_bias) {
+                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], ones, accb[i], 0, 0, 0);
+                    if (LA) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], ones, accb[i], 0, 0, 0);
+                }
+            }
+        }
+        buf ^= 1;
+    };
+    static_assert(GEMM_PF == 3, "the ring below is written out for three slots");
+    fetch_all(std::integral_constant<int, 0>{}, kbeg);
+    fetch_all(std::integral_constant<int, 1>{}, kbeg + BK);
+    fetch_all(std::integral_constant<int, 2>{}, kbeg + 2 * BK);
+    int buf = 0;
+    for (int k0 = kbeg;;) {
+        tile(std::integral_constant<int, 0>{}, k0, buf);
+        if (k0 + BK >= kend) break;
+        tile(std::integral_constant<int, 1>{}, k0 + BK, buf);
+        if (k0 + 2 * BK >= kend) break;
+        tile(std::integral_constant<int, 2>{}, k0 + 2 * BK, buf);
+        k0 += GEMM_PF * BK;
+        if (k0 >= kend) break;
+    }
+
     const EP ep = epi_for_slice(G.e, args.ksplit > 0 ? by : 0);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {

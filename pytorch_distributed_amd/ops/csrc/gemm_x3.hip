@@ -31,7 +31,7 @@ bool small_grid(int M, int N, int groups) {
 
 }  // namespace
 
-// ---- conv1 forward from uint8 frames: K' = 2 K ------------------------------------------------------
+// ---- conv1 forward from uint8 frames (exact in bf16: two products per pair) ----
 PDA_EXPORT void pda_x3_conv_fwd_u8(const void* const* frames, const void* const* idx, const void* const* w,
                                    long w_plane, const void* const* bias, void* const* out, long out_plane,
                                    int ngroups, int batch, int H, int W, int C, int KH, int KW, int S, int O,
@@ -43,10 +43,10 @@ PDA_EXPORT void pda_x3_conv_fwd_u8(const void* const* frames, const void* const*
         a.g[i].a = {{(const uint8_t*)frames[i], (const int*)idx[i], (long)C * H * W, g, M, K}, 0, K};
         a.g[i].b = {{(const bf16_t*)w[i], (long)K, O, K}, w_plane, K};
         a.g[i].e = {(bf16_t*)out[i], nullptr, (const float*)bias[i], scale, act, (long)O, 0, out_plane};
-        a.g[i].M = M; a.g[i].N = O; a.g[i].K = 2 * K;
+        a.g[i].M = M; a.g[i].N = O; a.g[i].K = K;
     }
-    if (O <= 32) launch_gemm<64, 32, 4, 1>(a, ngroups, M, O, 2 * K, 0, stream);
-    else launch_gemm<64, 64, 2, 2>(a, ngroups, M, O, 2 * K, 0, stream);
+    if (O <= 32) launch_gemm<64, 32, 4, 1>(a, ngroups, M, O, K, 0, stream);
+    else launch_gemm<64, 64, 2, 2>(a, ngroups, M, O, K, 0, stream);
 }
 
 // ---- conv forward on split NHWC activations ------------------------------------------------------------
@@ -60,11 +60,11 @@ PDA_EXPORT void pda_x3_conv_fwd(const void* const* x, long x_plane, const void* 
         a.g[i].a = {{(const bf16_t*)x[i], g, M, K}, x_plane, K};
         a.g[i].b = {{(const bf16_t*)w[i], (long)K, O, K}, w_plane, K};
         a.g[i].e = {(bf16_t*)out[i], nullptr, (const float*)bias[i], 1.f, act, (long)O, 0, out_plane};
-        a.g[i].M = M; a.g[i].N = O; a.g[i].K = 3 * K;
+        a.g[i].M = M; a.g[i].N = O; a.g[i].K = K;
     }
-    if (O <= 32) launch_gemm<64, 32, 4, 1>(a, ngroups, M, O, 3 * K, 0, stream);
-    else if (small_grid(M, O, ngroups)) launch_gemm<32, 64, 1, 4>(a, ngroups, M, O, 3 * K, 0, stream);
-    else launch_gemm<64, 64, 2, 2>(a, ngroups, M, O, 3 * K, 0, stream);
+    if (O <= 32) launch_gemm<64, 32, 4, 1>(a, ngroups, M, O, K, 0, stream);
+    else if (small_grid(M, O, ngroups)) launch_gemm<32, 64, 1, 4>(a, ngroups, M, O, K, 0, stream);
+    else launch_gemm<64, 64, 2, 2>(a, ngroups, M, O, K, 0, stream);
 }
 
 // ---- linear forward, split-K: partial sums into fp32 out32 -------------------------------------------
@@ -81,9 +81,9 @@ PDA_EXPORT void pda_x3_linear_fwd(const void* const* x, long x_plane, const void
             a.g[i].a = {{(const bf16_t*)x[i], ldx, M, K}, x_plane, K};
             a.g[i].b = {{(const bf16_t*)w[i], ldw, N, K}, w_plane, K};
             a.g[i].e = {(float*)out32[i], ldo32, slice_stride};
-            a.g[i].M = M; a.g[i].N = N; a.g[i].K = 3 * K;
+            a.g[i].M = M; a.g[i].N = N; a.g[i].K = K;
         }
-        int3 grid = plan_gemm<64, 64>(a, ngroups, M, N, 3 * K, ksplit > 0 ? ksplit : 3 * K);
+        int3 grid = plan_gemm<64, 64>(a, ngroups, M, N, K, ksplit > 0 ? ksplit : K);
         int units = grid.y * grid.z;
         hipLaunchKernelGGL((gemm_xcd_kernel<64, 64, 2, 2, GEMM_BK, SA, SB, EpiSlabF32>),
                            dim3((units + 7) / 8 * 8 * grid.x), dim3(GEMM_THREADS), 0, stream, a, grid);
@@ -94,9 +94,9 @@ PDA_EXPORT void pda_x3_linear_fwd(const void* const* x, long x_plane, const void
         a.g[i].a = {{(const bf16_t*)x[i], ldx, M, K}, x_plane, K};
         a.g[i].b = {{(const bf16_t*)w[i], ldw, N, K}, w_plane, K};
         a.g[i].e = {(float*)out32[i], ldo32, 1.f};
-        a.g[i].M = M; a.g[i].N = N; a.g[i].K = 3 * K;
+        a.g[i].M = M; a.g[i].N = N; a.g[i].K = K;
     }
-    launch_gemm<64, 64, 2, 2>(a, ngroups, M, N, 3 * K, ksplit > 0 ? ksplit : 3 * K, stream);
+    launch_gemm<64, 64, 2, 2>(a, ngroups, M, N, K, ksplit > 0 ? ksplit : K, stream);
 }
 
 // ---- data gradient of a linear map --------------------------------------------------------------------
@@ -107,9 +107,9 @@ PDA_EXPORT void pda_x3_linear_dgrad(const void* dy, long dy_plane, const void* w
     a.g[0].a = {{(const bf16_t*)dy, lddy, M, Nout}, dy_plane, Nout};
     a.g[0].b = {{(const bf16_t*)w, ldw, Kin, Nout}, w_plane, Nout};
     a.g[0].e = {(bf16_t*)dx, (const bf16_t*)y, y ? act : ACT_NONE, lddx, ldy, dx_plane};
-    a.g[0].M = M; a.g[0].N = Kin; a.g[0].K = 3 * Nout;
-    if (M <= 32 || small_grid(M, Kin, 1)) launch_gemm<32, 64, 1, 4>(a, 1, M, Kin, 3 * Nout, 0, stream);
-    else launch_gemm<64, 64, 2, 2>(a, 1, M, Kin, 3 * Nout, 0, stream);
+    a.g[0].M = M; a.g[0].N = Kin; a.g[0].K = Nout;
+    if (M <= 32 || small_grid(M, Kin, 1)) launch_gemm<32, 64, 1, 4>(a, 1, M, Kin, Nout, 0, stream);
+    else launch_gemm<64, 64, 2, 2>(a, 1, M, Kin, Nout, 0, stream);
 }
 
 // ---- conv data gradient, gather form (see pda_conv_dgrad) -------------------------------------------
@@ -129,13 +129,13 @@ PDA_EXPORT void pda_x3_conv_dgrad(const void* dy, long dy_plane, const void* w, 
             a.g[ng].a = {{(const bf16_t*)dy, g, M, K}, dy_plane, K};
             a.g[ng].b = {{(const bf16_t*)w, g, C, K}, w_plane, K};
             a.g[ng].e = {(bf16_t*)dx, (const bf16_t*)yin, yin ? act : ACT_NONE, g, dx_plane};
-            a.g[ng].M = M; a.g[ng].N = C; a.g[ng].K = 3 * K;
+            a.g[ng].M = M; a.g[ng].N = C; a.g[ng].K = K;
             maxM = M > maxM ? M : maxM;
             ++ng;
         }
-    if (C <= 32) launch_gemm<64, 32, 4, 1>(a, ng, maxM, C, 3 * K, 0, stream);
-    else if (small_grid(maxM, C, ng)) launch_gemm<32, 64, 1, 4>(a, ng, maxM, C, 3 * K, 0, stream);
-    else launch_gemm<64, 64, 2, 2>(a, ng, maxM, C, 3 * K, 0, stream);
+    if (C <= 32) launch_gemm<64, 32, 4, 1>(a, ng, maxM, C, K, 0, stream);
+    else if (small_grid(maxM, C, ng)) launch_gemm<32, 64, 1, 4>(a, ng, maxM, C, K, 0, stream);
+    else launch_gemm<64, 64, 2, 2>(a, ng, maxM, C, K, 0, stream);
 }
 
 // ---- weight gradients (split-K slabs, plain stores; see gemm.hip) -------------------------------------
@@ -150,11 +150,11 @@ PDA_EXPORT void pda_x3_linear_wgrad2(const void* const* dy, const long* dy_plane
         a.g[i].a = {{(const bf16_t*)dy[i], lddy[i], Nout[i], B}, dy_plane[i], B};
         a.g[i].b = {{(const bf16_t*)x[i], ldx[i], Kin[i], B}, x_plane[i], B};
         a.g[i].e = {(float*)gw[i], (float*)gb[i], ldg[i], 0, 0, 1.f};
-        a.g[i].M = Nout[i]; a.g[i].N = Kin[i]; a.g[i].K = 3 * B;
+        a.g[i].M = Nout[i]; a.g[i].N = Kin[i]; a.g[i].K = B;
         maxM = Nout[i] > maxM ? Nout[i] : maxM;
         maxN = Kin[i] > maxN ? Kin[i] : maxN;
     }
-    launch_gemm<64, 64, 2, 2>(a, n < 2 ? n : 2, maxM, maxN, 3 * B, 0, stream);
+    launch_gemm<64, 64, 2, 2>(a, n < 2 ? n : 2, maxM, maxN, B, 0, stream);
 }
 
 // fc backward in one launch: one linear data gradient (32-row tiles) + the two weight gradients above
@@ -173,19 +173,19 @@ PDA_EXPORT void pda_x3_fc_backward_duo(const void* d_dy, long d_dy_plane, const 
     a1.g[0].a = {{(const bf16_t*)d_dy, lddy, M, Nout}, d_dy_plane, Nout};
     a1.g[0].b = {{(const bf16_t*)d_w, ldw, Kin, Nout}, d_w_plane, Nout};
     a1.g[0].e = {(bf16_t*)d_dx, (const bf16_t*)d_y, d_y ? act : ACT_NONE, lddx, ldy, d_dx_plane};
-    a1.g[0].M = M; a1.g[0].N = Kin; a1.g[0].K = 3 * Nout;
-    int3 g1 = plan_gemm<32, 64>(a1, 1, M, Kin, 3 * Nout, 0);
+    a1.g[0].M = M; a1.g[0].N = Kin; a1.g[0].K = Nout;
+    int3 g1 = plan_gemm<32, 64>(a1, 1, M, Kin, Nout, 0);
     GemmArgs<SA2, SB2, EpiWgrad> a2;
     int maxM = 0, maxN = 0;
     for (int i = 0; i < 2; ++i) {
         a2.g[i].a = {{(const bf16_t*)dy[i], wlddy[i], wNout[i], B}, dy_plane[i], B};
         a2.g[i].b = {{(const bf16_t*)x[i], wldx[i], wKin[i], B}, x_plane[i], B};
         a2.g[i].e = {(float*)gw[i], (float*)gb[i], wldg[i], 0, 0, 1.f};
-        a2.g[i].M = wNout[i]; a2.g[i].N = wKin[i]; a2.g[i].K = 3 * B;
+        a2.g[i].M = wNout[i]; a2.g[i].N = wKin[i]; a2.g[i].K = B;
         maxM = wNout[i] > maxM ? wNout[i] : maxM;
         maxN = wKin[i] > maxN ? wKin[i] : maxN;
     }
-    int3 g2 = plan_gemm<64, 64>(a2, 2, maxM, maxN, 3 * B, 0);
+    int3 g2 = plan_gemm<64, 64>(a2, 2, maxM, maxN, B, 0);
     const int xcd = g1.y == 1 && g2.y == 1;
     int blocks = xcd ? xcd_cols_blocks(g1, a1.tiles_n) + xcd_cols_blocks(g2, a2.tiles_n)
                      : g1.x * g1.y * g1.z + g2.x * g2.y * g2.z;
@@ -208,9 +208,9 @@ PDA_EXPORT void pda_x3_conv_wgrad(const void* const* dy, const long* dy_plane, c
         a.g[i].a = {{(const bf16_t*)dy[i], (long)O, O, M}, dy_plane[i], M};
         a.g[i].b = {{(const bf16_t*)x[i], g, K, M}, x_plane[i], M};
         a.g[i].e = {(float*)gw[i], (float*)gb[i], (long)K, slice_stride[i], bslice_stride[i], 1.f};
-        a.g[i].M = O; a.g[i].N = K; a.g[i].K = 3 * M;
+        a.g[i].M = O; a.g[i].N = K; a.g[i].K = M;
         if (K > maxN) maxN = K;
-        if (3 * M > maxK) maxK = 3 * M;
+        if (M > maxK) maxK = M;
     }
     if (O <= 32) { launch_gemm<32, 64, 1, 4>(a, n, O, maxN, maxK, ksplit, stream); return; }
     int3 grid = plan_gemm<64, 64>(a, n, O, maxN, maxK, ksplit);
@@ -230,7 +230,7 @@ PDA_EXPORT void pda_x3_conv_wgrad_u8(const void* dy, long dy_plane, const void* 
     a.g[0].a = {{(const bf16_t*)dy, (long)O, O, M}, dy_plane, M};
     a.g[0].b = {{(const uint8_t*)frames, (const int*)idx, (long)C * H * W, g, K, M}, 0, M};
     a.g[0].e = {(float*)gw, (float*)gb, (long)K, slice_stride, bslice_stride, scale};
-    a.g[0].M = O; a.g[0].N = K; a.g[0].K = 2 * M;
-    if (O <= 32) launch_gemm<32, 64, 1, 4>(a, 1, O, K, 2 * M, ksplit, stream);
-    else launch_gemm<64, 64, 2, 2>(a, 1, O, K, 2 * M, ksplit, stream);
+    a.g[0].M = O; a.g[0].N = K; a.g[0].K = M;
+    if (O <= 32) launch_gemm<32, 64, 1, 4>(a, 1, O, K, M, ksplit, stream);
+    else launch_gemm<64, 64, 2, 2>(a, 1, O, K, M, ksplit, stream);
 }

@@ -284,7 +284,7 @@ def cnn_forward(geom, nets, frames, idxs, acts, B, norm_val, keep_first_only=Tru
             return
         tiles = ((B + 63) // 64) * (g.HID // 64) * n
         nn.x3_linear_fwd(acts.a3[:n], [w.w[3] for w in nets], acts.h1pre[:n], B, g.HID, g.F, g.F, g.F, g.HID,
-                         ksplit=_ksplit(3 * g.F, tiles, _FC1_BLOCKS, 128))
+                         ksplit=_ksplit(g.F, tiles, _FC1_BLOCKS, 128))
         return
     if nn.cnn_fwd_stack_supported(g.H, g.W, g.C):
         # one launch, one workgroup per image; only group 0 (the trained network on s0) keeps a1 / a2
@@ -312,7 +312,7 @@ def fc1_slabs(acts, geom, B, groups, device):
     """Switch fc1's forward split-K from fp32 atomics into one buffer to slabs [slices][B][HID] per network that
     the head kernel adds in slice order: bit-reproducible steps, no memory-side atomics, nothing to zero."""
     g = geom
-    mult = 3 if acts.split else 1
+    mult = 1        # (split operands: the x3 GEMM body reduces over the logical K, csrc/gemm.h gemm_body_x3)
     tiles = ((B + 63) // 64) * (g.HID // 64) * groups
     ks = _ksplit(mult * g.F, tiles, _FC1_BLOCKS, 128)
     acts.h1_ksplit = ks
@@ -395,13 +395,13 @@ class DqnCnnEngine(object):
         g, B, dev = self.geom, self.B, self.device
         plans = []      # (layer, O, K, red)
         # fp32 precision: the reduction carries the operand copies (gemm.h SrcSplit): x2 against uint8 frames, else x3
-        mult = (2, 3, 3) if self.x3 else (1, 1, 1)
+        mult = (1, 1, 1)        # reductions are in logical units for the split-operand kernels too (gemm_body_x3)
         for li, (O, K, red) in enumerate([(32, g.K1, mult[0] * B * g.H1 * g.W1), (64, g.K2, mult[1] * B * g.H2 * g.W2),
                                           (64, g.K3, mult[2] * B * g.P3)]):
             tiles = ((O + 63) // 64 if O > 32 else 1) * ((K + 63) // 64)
             # (fp32 precision: the reductions are 2-3 x longer; more, shorter slices measured 3.51k -> 3.77k updates/s)
-            wg_blocks = _WGRAD_BLOCKS * (4 if self.x3 and "PDA_WGRAD_BLOCKS" not in os.environ else 1)
-            pair_blocks = _PAIR_BLOCKS * (2 if self.x3 and "PDA_PAIR_BLOCKS" not in os.environ else 1)
+            wg_blocks = _WGRAD_BLOCKS * (int(os.environ.get("PDA_X3_WGRAD_MULT", 2)) if self.x3 else 1)
+            pair_blocks = _PAIR_BLOCKS * (int(os.environ.get("PDA_X3_PAIR_MULT", 1)) if self.x3 else 1)
             ks = _ksplit(red, tiles, wg_blocks, 128)
             if li > 0 and self.stack_wgrad:
                 ks, ns_override = 0, nn.cnn_wgrad_stack_slices(B)      # per-image kernel: one slice per workgroup

@@ -88,7 +88,7 @@ def test_x3_conv_fwd_and_backward(nn, geom):
                F.relu(F.conv2d(xd.detach() * 0.5, wd.detach(), bd.detach(), stride=S))) < TOL
     # weight / bias gradient through split-K slabs
     K = C * KH * KW
-    red = 3 * batch * OH * OW
+    red = batch * OH * OW           # logical reduction length (the kernel stages hi and lo tiles per k-tile)
     ns = nn.num_slices(red, 512)
     slab = torch.full((ns, O * K), 7.0, device="cuda")
     bslab = torch.full((ns, O), 7.0, device="cuda")
@@ -117,7 +117,7 @@ def test_x3_conv_wgrad_pair_and_u8(nn):
         dy = torch.randn(batch, 64, OH, OW, device="cuda")
         wd = torch.zeros(64, C, KH, KW, device="cuda", dtype=torch.double, requires_grad=True)
         F.conv2d(x.double(), wd, None, stride=S).backward(dy.double())
-        ns = nn.num_slices(3 * batch * OH * OW, ks)
+        ns = nn.num_slices(batch * OH * OW, ks)
         dys.append(planes_nhwc(nn, dy))
         xs.append(planes_nhwc(nn, x))
         slabs.append(torch.full((ns, 64 * K), 7.0, device="cuda"))
@@ -133,7 +133,7 @@ def test_x3_conv_wgrad_pair_and_u8(nn):
     dy = torch.randn(batch, 32, 20, 20, device="cuda")
     wd = torch.zeros(32, 4, 8, 8, device="cuda", dtype=torch.double, requires_grad=True)
     F.conv2d(mem[idx.long()].double() / 255.0, wd, None, stride=4).backward(dy.double())
-    ns = nn.num_slices(2 * batch * 400, 512)
+    ns = nn.num_slices(batch * 400, 512)
     slab = torch.full((ns, 32 * 256), 7.0, device="cuda")
     bslab = torch.full((ns, 32), 7.0, device="cuda")
     nn.x3_conv_wgrad_u8(planes_nhwc(nn, dy), mem, idx, slab, bslab, batch, 84, 84, 4, 8, 8, 4, 32, 1.0 / 255.0,
