@@ -47,27 +47,39 @@ __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
     long row = (long)b * HID + lane * PER;
 
     // The replay row (index -> tail record -> action -> that action's W5 row) is a chain of three dependent
-    // global loads.  It is started here, ahead of everything else and ahead of the zeroing stores below
-    // (which the compiler will not move loads across), so that it runs under the hidden-row loads and the
-    // dot products instead of after them.
+    // global loads, and a wave issues in order: every s_waitcnt on that chain also holds back the loads behind it.
+    // So the chain is interleaved with the independent work instead of run ahead of it: the index load goes out
+    // first and is only consumed after the hidden-row sums (whose loads are then already in flight), the tail
+    // record is fetched before the fc2 dot products and consumed after them, and the action's W5 row is re-read
+    // at the very end, when this wave has just pulled all of W5 through its L1.
     const int ridx = p.idx ? p.idx[b] : b;
-    const float* tl = p.tails + (long)ridx * p.tail_ld;
-    const float t_act = tl[p.off_action], t_rew = tl[p.off_reward], t_gam = tl[p.off_gamma], t_term = tl[p.off_term];
-    const int act = min(max((int)t_act, 0), p.A - 1);
     const float w = p.isw ? p.isw[b] : 1.f;
-    float wa[PER];
-    {
-        const float* w_act = p.w5_on + (long)act * HID + lane * PER;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) wa[j] = w_act[j];
-    }
 
     float h0[PER], ht[PER], hd[PER];
     if (p.h1_slices > 0) {
         // slabs: PER consecutive floats per lane and slice (16-byte loads), summed in slice order
         typedef float vecf __attribute__((ext_vector_type(PER)));
         vecf a0 = {}, at = {}, ad = {};
-        for (int sl = 0; sl < p.h1_slices; ++sl) {
+        // four slices per round trip: the loads of a group are all issued before the first add (one slice per
+        // iteration was a chain of h1_slices dependent memory latencies on 128 waves -- most of this kernel's 9 us)
+        int sl = 0;
+        for (; sl + 4 <= p.h1_slices; sl += 4) {
+            vecf v0[4], vt[4], vd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long o = (long)(sl + u) * p.h1_slice_stride + row;
+                v0[u] = *reinterpret_cast<const vecf*>(p.h1pre_on0 + o);
+                vt[u] = *reinterpret_cast<const vecf*>(p.h1pre_tg1 + o);
+                if (p.h1pre_on1) vd[u] = *reinterpret_cast<const vecf*>(p.h1pre_on1 + o);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {       // slice order: bit-reproducible
+                a0 += v0[u];
+                at += vt[u];
+                if (p.h1pre_on1) ad += vd[u];
+            }
+        }
+        for (; sl < p.h1_slices; ++sl) {
             const long o = (long)sl * p.h1_slice_stride + row;
             a0 += *reinterpret_cast<const vecf*>(p.h1pre_on0 + o);
             at += *reinterpret_cast<const vecf*>(p.h1pre_tg1 + o);
@@ -90,6 +102,9 @@ __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
             if (p.h1pre_on1) p.h1pre_on1[row + j] = 0.f;
         }
     }
+
+    const float* tl = p.tails + (long)ridx * p.tail_ld;
+    const float t_act = tl[p.off_action], t_rew = tl[p.off_reward], t_gam = tl[p.off_gamma], t_term = tl[p.off_term];
 
     // lane a keeps q(.)[a]: no runtime-indexed arrays (they would live in scratch).  Actions go in
     // groups of 8 with the 24 dot products formed first and reduced together, so the shuffles of
@@ -133,6 +148,13 @@ __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
         }
     }
     float next_q = p.h1pre_on1 ? __shfl(myqt, arg_d, 64) : best_t;
+    const int act = min(max((int)t_act, 0), p.A - 1);
+    float wa[PER];
+    {
+        const float* w_act = p.w5_on + (long)act * HID + lane * PER;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) wa[j] = w_act[j];
+    }
 
     float y = t_rew + t_gam * next_q * (1.f - t_term);
     float td = __shfl(myq0, act, 64) - y;
