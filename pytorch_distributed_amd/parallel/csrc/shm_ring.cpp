@@ -12,9 +12,17 @@
 // `tail` when slot.seq == pos + 1, reads, then frees with slot.seq = pos + N.
 // No syscalls, no locks; a stalled producer only delays its own slot.
 //
+// A producer that DIES between its claim and its publish (fault injection, OOM kill, the supervisor's terminate())
+// would leave the slot unpublished for good and the consumer stuck behind it.  So a claim also records the
+// claimant's pid in the slot; a consumer that finds the slot at `tail` claimed but unpublished for longer than
+// Header::stuck_ms skips it when that process no longer exists (kill(pid, 0) == ESRCH), or when no pid was recorded
+// yet (death between the two stores).  A live, merely slow producer is never skipped.
+//
 // The region is plain memory (a torch shared-memory tensor on the Python side),
 // so the same code works across spawn'ed processes.  C ABI for ctypes.
 #include <atomic>
+#include <cerrno>
+#include <csignal>
 #include <cstdint>
 #include <cstring>
 #include <chrono>
@@ -34,17 +42,26 @@ struct alignas(kLine) Header {
     uint32_t num_slots;      // power of two
     uint32_t payload_bytes;  // bytes copied per record
     uint32_t slot_stride;    // bytes between slots (header + padded payload)
-    uint32_t reserved;
+    uint32_t stuck_ms;       // how long the consumer lets a claimed, unpublished slot block the tail (see above)
     alignas(kLine) std::atomic<uint64_t> head;
     alignas(kLine) std::atomic<uint64_t> tail;
     alignas(kLine) std::atomic<uint64_t> pushed;
     alignas(kLine) std::atomic<uint64_t> popped;
     alignas(kLine) std::atomic<uint64_t> full_events;
+    alignas(kLine) std::atomic<uint64_t> skipped;       // slots abandoned by dead producers
+    std::atomic<uint64_t> stuck_pos;                    // consumer side: the tail position that was found blocked ...
+    std::atomic<uint64_t> stuck_since_ms;               // ... and when (steady clock, ms)
 };
 
 struct alignas(kLine) Slot {
     std::atomic<uint64_t> seq;
+    std::atomic<uint32_t> owner;        // pid of the producer between claim and publish, else 0
 };
+
+inline uint64_t now_ms() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(
+               std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 static_assert(std::atomic<uint64_t>::is_always_lock_free, "need lock-free 64-bit atomics");
 
@@ -56,6 +73,21 @@ inline Slot* slot_at(void* base, uint64_t pos) {
     return reinterpret_cast<Slot*>(slots_base(base) + (pos & (h->num_slots - 1)) * (size_t)h->slot_stride);
 }
 inline char* payload_of(Slot* s) { return reinterpret_cast<char*>(s) + sizeof(Slot); }
+
+// The slot at tail position `pos` is claimed (head > pos) but not published.  True once that has lasted stuck_ms
+// AND its claimant is gone.
+inline bool abandoned(Header* h, Slot* s, uint64_t pos) {
+    const uint64_t t = now_ms();
+    if (h->stuck_pos.load(std::memory_order_relaxed) != pos) {
+        h->stuck_pos.store(pos, std::memory_order_relaxed);
+        h->stuck_since_ms.store(t, std::memory_order_relaxed);
+        return false;
+    }
+    if (t - h->stuck_since_ms.load(std::memory_order_relaxed) < h->stuck_ms) return false;
+    const uint32_t pid = s->owner.load(std::memory_order_relaxed);
+    if (pid == 0) return true;                              // died between the claim and the owner store
+    return kill((pid_t)pid, 0) != 0 && errno == ESRCH;      // the claimant no longer exists
+}
 
 }  // namespace
 
@@ -80,9 +112,14 @@ int pda_ring_init(void* base, uint64_t region_bytes, uint32_t num_slots, uint32_
     h->pushed.store(0, std::memory_order_relaxed);
     h->popped.store(0, std::memory_order_relaxed);
     h->full_events.store(0, std::memory_order_relaxed);
+    h->skipped.store(0, std::memory_order_relaxed);
+    h->stuck_pos.store(~0ull, std::memory_order_relaxed);
+    h->stuck_since_ms.store(0, std::memory_order_relaxed);
+    h->stuck_ms = 2000;
     for (uint32_t i = 0; i < num_slots; ++i) {
         Slot* s = new (slots_base(base) + (size_t)i * h->slot_stride) Slot();
         s->seq.store(i, std::memory_order_relaxed);
+        s->owner.store(0, std::memory_order_relaxed);
     }
     std::atomic_thread_fence(std::memory_order_seq_cst);
     h->magic = kMagic;
@@ -112,11 +149,13 @@ int pda_ring_push(void* base, const void* seg0, uint32_t n0, const void* seg1, u
             pos = h->head.load(std::memory_order_relaxed);
         }
     }
+    s->owner.store((uint32_t)getpid(), std::memory_order_relaxed);
     char* dst = payload_of(s);
     if (n0) { std::memcpy(dst, seg0, n0); dst += n0; }
     if (n1) { std::memcpy(dst, seg1, n1); dst += n1; }
     if (n2) { std::memcpy(dst, seg2, n2); dst += n2; }
     if (n3) { std::memcpy(dst, seg3, n3); }
+    s->owner.store(0, std::memory_order_relaxed);
     s->seq.store(pos + 1, std::memory_order_release);
     h->pushed.fetch_add(1, std::memory_order_relaxed);
     return 1;
@@ -139,6 +178,16 @@ int pda_ring_pop_many(void* base, void* dst, uint32_t dst_stride, uint32_t max_r
             if (dif == 0) {
                 if (h->tail.compare_exchange_weak(pos, pos + 1, std::memory_order_relaxed)) break;
             } else if (dif < 0) {
+                // not published.  Empty ring (nobody claimed `pos`), a producer still copying, or one that died?
+                if (h->head.load(std::memory_order_relaxed) > pos && abandoned(h, s, pos)) {
+                    if (h->tail.compare_exchange_strong(pos, pos + 1, std::memory_order_relaxed)) {
+                        s->owner.store(0, std::memory_order_relaxed);
+                        s->seq.store(pos + h->num_slots, std::memory_order_release);
+                        h->skipped.fetch_add(1, std::memory_order_relaxed);
+                    }
+                    pos = h->tail.load(std::memory_order_relaxed);
+                    continue;
+                }
                 empty = true;
                 break;
             } else {
@@ -157,6 +206,28 @@ int pda_ring_pop_many(void* base, void* dst, uint32_t dst_stride, uint32_t max_r
 uint64_t pda_ring_pushed(void* base) { return hdr(base)->pushed.load(std::memory_order_relaxed); }
 uint64_t pda_ring_popped(void* base) { return hdr(base)->popped.load(std::memory_order_relaxed); }
 uint64_t pda_ring_full_events(void* base) { return hdr(base)->full_events.load(std::memory_order_relaxed); }
+uint64_t pda_ring_skipped(void* base) { return hdr(base)->skipped.load(std::memory_order_relaxed); }
+void pda_ring_set_stuck_ms(void* base, uint32_t ms) { hdr(base)->stuck_ms = ms; }
+// Test hook: claim the next slot as this process and never publish it (what a producer killed mid-copy leaves behind).
+// Returns the claimed position, or -1 if the ring is full.
+int64_t pda_ring_claim_and_abandon(void* base) {
+    Header* h = hdr(base);
+    uint64_t pos = h->head.load(std::memory_order_relaxed);
+    for (;;) {
+        Slot* s = slot_at(base, pos);
+        int64_t dif = (int64_t)(s->seq.load(std::memory_order_acquire) - pos);
+        if (dif == 0) {
+            if (h->head.compare_exchange_weak(pos, pos + 1, std::memory_order_relaxed)) {
+                s->owner.store((uint32_t)getpid(), std::memory_order_relaxed);
+                return (int64_t)pos;
+            }
+        } else if (dif < 0) {
+            return -1;
+        } else {
+            pos = h->head.load(std::memory_order_relaxed);
+        }
+    }
+}
 uint64_t pda_ring_backlog(void* base) {
     Header* h = hdr(base);
     uint64_t hd = h->head.load(std::memory_order_relaxed), tl = h->tail.load(std::memory_order_relaxed);

@@ -47,7 +47,12 @@ def lib():
         L.pda_ring_push.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, u32]
         L.pda_ring_pop_many.restype = i32
         L.pda_ring_pop_many.argtypes = [vp, vp, u32, u32]
-        for name in ("pda_ring_pushed", "pda_ring_popped", "pda_ring_full_events", "pda_ring_backlog"):
+        L.pda_ring_set_stuck_ms.restype = None
+        L.pda_ring_set_stuck_ms.argtypes = [vp, u32]
+        L.pda_ring_claim_and_abandon.restype = ctypes.c_int64
+        L.pda_ring_claim_and_abandon.argtypes = [vp]
+        for name in ("pda_ring_pushed", "pda_ring_popped", "pda_ring_full_events", "pda_ring_backlog",
+                     "pda_ring_skipped"):
             getattr(L, name).restype = u64
             getattr(L, name).argtypes = [vp]
         L.pda_atomic_load.restype = u64

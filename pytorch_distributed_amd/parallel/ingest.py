@@ -104,4 +104,5 @@ class ShmRing(object):
     def stats(self):
         L = hostlib.lib()
         return {"pushed": int(L.pda_ring_pushed(self.base)), "popped": int(L.pda_ring_popped(self.base)),
-                "full_events": int(L.pda_ring_full_events(self.base)), "backlog": int(L.pda_ring_backlog(self.base))}
+                "full_events": int(L.pda_ring_full_events(self.base)), "backlog": int(L.pda_ring_backlog(self.base)),
+                "skipped": int(L.pda_ring_skipped(self.base))}
