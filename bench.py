@@ -343,6 +343,16 @@ def run_rank(a):
         extra["dp_param_max_abs_diff_across_ranks"] = reduce_max(float((mine - ref).abs().max().item()))
         extra["dp_graph"] = getattr(prog, "dp_graph_mode", None)
         extra["dp_allreduce"] = getattr(prog, "allreduce_kind", getattr(comm, "backend", None))
+        # the peer kernel's spins are bounded: a wait that ran out sets an error word instead of hanging the GPU
+        errs = 0
+        for pr in [getattr(c[0], "program", None) for c in cores.values()]:
+            for ar in (getattr(pr, "ar_tail", None), getattr(pr, "ar_head", None)):
+                if ar is not None and hasattr(ar, "error"):
+                    errs += int(bool(ar.error()))
+        extra["dp_allreduce_errors"] = int(reduce_max(float(errs)))
+        if extra["dp_allreduce_errors"] and rank == 0:
+            print("[bench] the peer all-reduce reported timed-out waits: the DP result is NOT valid; rerun with "
+                  "--allreduce rccl", file=sys.stderr, flush=True)
     if a.actor_bench and rank == 0 and a.compute == "native":
         from pytorch_distributed_amd.ops.dqn_engine import DqnCnnInference
         for nact in (8, 256):

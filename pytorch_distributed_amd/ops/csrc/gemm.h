@@ -29,7 +29,9 @@
 #include "common.h"
 #include <type_traits>
 
+#ifndef GEMM_BK
 #define GEMM_BK 64          // default k-tile (elements); a template parameter of the kernel
+#endif
 #define GEMM_PF 3           // k-tiles of global loads kept in flight ahead of the MFMAs (register ring)
 #define GEMM_THREADS 256
 #define GEMM_MAX_GROUPS 8

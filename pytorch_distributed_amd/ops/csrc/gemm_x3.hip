@@ -10,6 +10,9 @@
 // Convention: a tensor argument `t` with `t_plane` = element offset from its hi plane to its lo plane.
 // Activations / activation gradients enter as A = (hi, lo, hi), weights as B = (hi, hi, lo); uint8 frames are
 // exact in bf16 and enter twice against (hi, lo) of the other operand.
+#ifdef PDA_X3_BK
+#define GEMM_BK PDA_X3_BK
+#endif
 #include "gemm.h"
 #include "api.h"
 #include <cstdlib>

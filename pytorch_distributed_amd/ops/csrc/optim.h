@@ -163,15 +163,23 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
                     v4[it] = *reinterpret_cast<const float4*>(v + gbase0 + q);
                 }
             }
+            // P odd (fc1: 49, conv3: 9): pitch == P, the LDS image of the row IS the master row, so it goes in and
+            // out as 16-byte vectors.  (Scalar stores of the four components are stride-4 across lanes: 16 banks
+            // for 64 lanes, the 64 % bank-conflict rate of this kernel in profiles/r2_b128_bf16_counters.txt.)
+            const bool flat_row = pitch == P;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 int i = (threadIdx.x + it * 256) * 4;
                 if (i < s.cols) {
-                    const float e4[4] = {a4[it].x, a4[it].y, a4[it].z, a4[it].w};
+                    if (flat_row) {
+                        *reinterpret_cast<float4*>(row + i) = a4[it];
+                    } else {
+                        const float e4[4] = {a4[it].x, a4[it].y, a4[it].z, a4[it].w};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        int c = (i + k) / P, pp = (i + k) - c * P;
-                        row[c * pitch + pp] = e4[k];
+                        for (int k = 0; k < 4; ++k) {
+                            int c = (i + k) / P, pp = (i + k) - c * P;
+                            row[c * pitch + pp] = e4[k];
+                        }
                     }
                 }
             }
@@ -213,13 +221,17 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
             for (int it = 0; it < IT; ++it) {
                 int i = (threadIdx.x + it * 256) * 4;
                 if (i < s.cols) {
-                    float e4[4];
+                    if (flat_row) {
+                        *reinterpret_cast<float4*>(prow + i) = *reinterpret_cast<const float4*>(row + i);
+                    } else {
+                        float e4[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        int c = (i + k) / P, pp = (i + k) - c * P;
-                        e4[k] = row[c * pitch + pp];
+                        for (int k = 0; k < 4; ++k) {
+                            int c = (i + k) / P, pp = (i + k) - c * P;
+                            e4[k] = row[c * pitch + pp];
+                        }
+                        *reinterpret_cast<float4*>(prow + i) = make_float4(e4[0], e4[1], e4[2], e4[3]);
                     }
-                    *reinterpret_cast<float4*>(prow + i) = make_float4(e4[0], e4[1], e4[2], e4[3]);
                 }
             }
             return;

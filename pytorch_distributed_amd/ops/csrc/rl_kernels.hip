@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    const int2* __restrict__ chunks, int nchunks,
                                                    const float* __restrict__ hyper,
                                                    const int* __restrict__ step, AdamExtras x) {
-    __shared__ float row[OPT_ROW_LDS];
+    __shared__ __attribute__((aligned(16))) float row[OPT_ROW_LDS];
     adam_block(p, g, m, v, shadow, segs, chunks, nchunks, hyper, step, x, (int)blockIdx.x, row);
 }
 
