@@ -36,6 +36,10 @@ PDA_EXPORT int pda_conv1_supported(int H, int W, int C, int KH, int KW, int S, i
 PDA_EXPORT void pda_conv1_fwd_u8(const void* const* frames, const void* const* idx, const void* const* w,
                                  const void* const* bias, void* const* out, int ngroups, int batch, int H, int W,
                                  int C, float scale, int act, hipStream_t stream);
+PDA_EXPORT void pda_conv1_fwd_u8_x3(const void* const* frames, const void* const* idx, const void* const* w,
+                                    long w_plane, const void* const* bias, void* const* out, long out_plane,
+                                    int ngroups, int batch, int H, int W, int C, float scale, int act,
+                                    hipStream_t stream);
 PDA_EXPORT int pda_cnn_fwd_stack_supported(int H, int W, int C);
 PDA_EXPORT void pda_cnn_fwd_stack(const void* const* frames, const void* const* idx, const void* const* w1,
                                   const void* const* b1, const void* const* w2, const void* const* b2,

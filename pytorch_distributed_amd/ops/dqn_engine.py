@@ -411,9 +411,9 @@ class DqnCnnEngine(object):
                 work = mult[1] * (8 * (B * g.H2 * g.W2) + 9 * (B * g.P3))
                 ks = nn.round_ksplit(max(128, (work + pair_blocks - 1) // pair_blocks))
             ns = nn.num_slices(red, ks) if ks > 0 else ns_override
-            if li == 0 and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32) and not self.x3:
+            if li == 0 and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32):
                 ns = nn.conv1_wgrad_slices(B)       # whole-image kernel: one slice per workgroup
-                if self.fuse_w1:
+                if self.fuse_w1 and not self.x3:
                     ns = nn.cnn_dgrad_stack_slices(B)   # computed by the dgrad stack launch itself
             plans.append((li, O, K, ks, ns))
         self.wg_plan = plans
@@ -565,8 +565,11 @@ class DqnCnnEngine(object):
             else:
                 nn.x3_conv_wgrad([a.da3], [a.a2[0]], [w3s], [b3s], B, geoms[1:], 64, ks3, [st3], [bst3])
                 nn.x3_conv_wgrad([a.da2], [a.a1[0]], [w2s], [b2s], B, geoms[:1], 64, ks2, [st2], [bst2])
-            nn.x3_conv_wgrad_u8(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / self.norm_val,
-                                ksplit=ks1, slice_stride=st1, bslice_stride=bst1)
+            if nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32):
+                nn.x3_conv1_wgrad_u8_whole(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 1.0 / self.norm_val, st1, bst1)
+            else:
+                nn.x3_conv_wgrad_u8(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / self.norm_val,
+                                    ksplit=ks1, slice_stride=st1, bslice_stride=bst1)
             if reduce:
                 self.reduce.run()
             return False

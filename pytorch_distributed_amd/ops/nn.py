@@ -551,9 +551,19 @@ def x3_conv_wgrad(dys, xs, gws, gbs, batch, geoms, O, ksplit, slice_strides, bsl
                            int(O), _longs(slice_strides), _longs(bslice_strides), int(ksplit), _stream())
 
 
+def x3_conv1_wgrad_u8_whole(dy, frames, idx, gw, gb, batch, H, W, C, scale, slice_stride, bslice_stride):
+    """conv1 weight gradient (dy split, frames exact) by the whole-image kernel: conv1_wgrad_slices(batch) slab slices."""
+    L = _L()
+    L.pda_conv1_wgrad_u8_x3.argtypes = [_vp, ctypes.c_long, _vp, _vp, _vp, _vp] + [ctypes.c_int] * 4 + \
+        [ctypes.c_float, ctypes.c_long, ctypes.c_long, _vp]
+    L.pda_conv1_wgrad_u8_x3.restype = None
+    L.pda_conv1_wgrad_u8_x3(_ptr(dy), _plane(dy), _ptr(frames), _ptr(idx), _ptr(gw), _ptr(gb), batch, H, W, C,
+                            float(scale), slice_stride, bslice_stride, _stream())
+
+
 def x3_conv_wgrad_u8(dy, frames, idx, gw, gb, batch, H, W, C, KH, KW, S, O, scale, ksplit=0, slice_stride=0,
                      bslice_stride=0):
-    """conv1 weight gradient: dy split, frames exact; reduction 2 * batch * OH * OW."""
+    """conv1 weight gradient: dy split, frames exact (generic implicit GEMM, split-K slabs)."""
     assert ksplit == 0 or slice_stride >= O * C * KH * KW
     _X().pda_x3_conv_wgrad_u8(_ptr(dy), _plane(dy), _ptr(frames), _ptr(idx), _ptr(gw), _ptr(gb), batch, H, W, C, KH,
                               KW, S, O, float(scale), slice_stride, bslice_stride, int(ksplit), _stream())

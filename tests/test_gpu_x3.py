@@ -140,6 +140,13 @@ def test_x3_conv_wgrad_pair_and_u8(nn):
                         ksplit=512, slice_stride=32 * 256, bslice_stride=32)
     assert rel(slab.sum(0).reshape(32, 4, 8, 8), wd.grad) < TOL
     assert rel(bslab.sum(0), dy.double().sum((0, 2, 3))) < TOL
+    # the same gradient by the whole-image kernel (frame stack in LDS, dy hi / lo tiles, one slab slice per workgroup)
+    ns = nn.conv1_wgrad_slices(batch)
+    slab = torch.full((ns, 32 * 256), 7.0, device="cuda")
+    bslab = torch.full((ns, 32), 7.0, device="cuda")
+    nn.x3_conv1_wgrad_u8_whole(planes_nhwc(nn, dy), mem, idx, slab, bslab, batch, 84, 84, 4, 1.0 / 255.0, 32 * 256, 32)
+    assert rel(slab.sum(0).reshape(32, 4, 8, 8), wd.grad) < TOL
+    assert rel(bslab.sum(0), dy.double().sum((0, 2, 3))) < TOL
 
 
 def test_x3_linear_family(nn):
