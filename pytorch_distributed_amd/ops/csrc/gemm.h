@@ -34,6 +34,30 @@
 #endif
 #define GEMM_PF 3           // k-tiles of global loads kept in flight ahead of the MFMAs (register ring)
 #define GEMM_THREADS 256
+// The k-loop of both workgroup programs: whole rounds of the three-slot ring in a loop with ONE exit, then the
+// 0-2 left-over tiles (which prefetch nothing).  Written with `break`s between the tiles, the loop's exits are
+// unified into its latch block and the compiler's s_waitcnt pass merges "left after the first tile" (slot 0
+// holds the NEWEST loads) into the loop header: the first commit of every round then waited for vmcnt(0),
+// draining the ring once per three tiles.
+#define GEMM_RING_LOOP                                                                               \
+    {                                                                                                \
+        typedef std::integral_constant<int, 0> S0;                                                   \
+        typedef std::integral_constant<int, 1> S1;                                                   \
+        typedef std::integral_constant<int, 2> S2;                                                   \
+        const int nt = (kend - kbeg + BK - 1) / BK, rounds = nt / GEMM_PF;                           \
+        int buf = 0, k0 = kbeg;                                                                      \
+        for (int r = 0; r < rounds; ++r) {                                                           \
+            tile(S0{}, std::true_type{}, k0, buf);                                                   \
+            tile(S1{}, std::true_type{}, k0 + BK, buf);                                              \
+            tile(S2{}, std::true_type{}, k0 + 2 * BK, buf);                                          \
+            k0 += GEMM_PF * BK;                                                                      \
+        }                                                                                            \
+        const int rem = nt - rounds * GEMM_PF;                                                       \
+        if (rem > 0) {                                                                               \
+            tile(S0{}, std::false_type{}, k0, buf);                                                  \
+            if (rem > 1) tile(S1{}, std::false_type{}, k0 + BK, buf);                                \
+        }                                                                                            \
+    }
 #define GEMM_MAX_GROUPS 8
 
 // ----------------------------------------------------------------------------
@@ -93,24 +117,54 @@ struct SrcDenseT {      // element(row, k) = p[k*ld + row]; row-contiguous
 };
 
 // NHWC bf16 activations viewed as im2col rows: row m = (b, oy, ox), k = (ky, kx, c)
-struct ConvGeom { int H, W, C, KH, KW, S, OH, OW; };
+// Exact n / d by one multiply-high: m = ceil(2^32 / d), valid while n * d < 2^32 (row and reduction indices of
+// every launch here: the launchers check).  The loaders used to divide at run time (v_rcp + ~25 VALU
+// instructions per quotient, two quotients per 16-byte load): at batch 128 the gather-form data gradients
+// spent their time on that arithmetic, not on memory or MFMA (profiles/r2_b128_fp32x3_v3_*: 3.5 % MFMA busy,
+// 34 % wait, ~1000 instructions per k-tile and wave).
+__host__ __device__ inline unsigned fastdiv_magic(int d) {
+    return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d);
+}
+// d == 1 has no 32-bit magic (m == 0 there): its quotient is added in arithmetically -- a uniform branch per
+// division otherwise
+__device__ __forceinline__ int fdiv(int n, int /*d*/, unsigned m) {
+    const unsigned one = m == 0u ? 0xffffffffu : 0u;
+    return (int)(__umulhi((unsigned)n, m) + ((unsigned)n & one));
+}
+// e when ok, else 0, as arithmetic: `ok ? e : 0` compiles to a divergent branch around e's multiplications
+__device__ __forceinline__ int keep_if(int e, bool ok) { return e & -(int)ok; }
+
+struct ConvGeom { int H, W, C, KH, KW, S, OH, OW; unsigned m_run, m_ohw, m_ow; };
+inline ConvGeom make_geom(int H, int W, int C, int KH, int KW, int S) {
+    ConvGeom g;
+    g.H = H; g.W = W; g.C = C; g.KH = KH; g.KW = KW; g.S = S;
+    g.OH = (H - KH) / S + 1;
+    g.OW = (W - KW) / S + 1;
+    g.m_run = fastdiv_magic(KW * C); g.m_ohw = fastdiv_magic(g.OH * g.OW); g.m_ow = fastdiv_magic(g.OW);
+    return g;
+}
 
 struct SrcIm2colK {
     static constexpr bool kT = false;
     const bf16_t* p; ConvGeom g; int rows; int red;
     struct Ctx { const bf16_t* base; bool ok; };
     __device__ __forceinline__ Ctx prep(int m) const {
+        bool ok = m < rows;
+        m = ok ? m : 0;
         int ohw = g.OH * g.OW;
-        int b = m / ohw, r = m - b * ohw;
-        int oy = r / g.OW, ox = r - oy * g.OW;
-        return {p + (((long)b * g.H + oy * g.S) * g.W + ox * g.S) * g.C, m < rows};
+        int b = fdiv(m, ohw, g.m_ohw), r = m - b * ohw;
+        int oy = fdiv(r, g.OW, g.m_ow), ox = r - oy * g.OW;
+        return {p + (((long)b * g.H + oy * g.S) * g.W + ox * g.S) * g.C, ok};
     }
     PDA_BF16_SOURCE_FINISH
+    // branch-free: an out-of-range lane reads its row's first 16 bytes (row 0's for a row past the end)
     __device__ __forceinline__ Raw raw_at(const Ctx& c, int k, int lim, bool& ok, long poff) const {
-        ok = c.ok && k < lim;
+        const bool kin = k < lim;
+        ok = c.ok & kin;
         int run = g.KW * g.C;
-        int ky = k / run, off = k - ky * run;
-        return *reinterpret_cast<const uint4*>((ok ? c.base + (long)ky * g.W * g.C + off : p) + poff);
+        int ky = fdiv(k, run, g.m_run), off = k - ky * run;
+        int e = keep_if(ky * (g.W * g.C) + off, kin);
+        return *reinterpret_cast<const uint4*>(c.base + poff + e);
     }
     PDA_SOURCE_RAW
 };
@@ -118,20 +172,23 @@ struct SrcIm2colK {
 struct SrcIm2colT {     // rows = k-columns of the im2col matrix (8 consecutive), reduction = m
     static constexpr bool kT = true;
     const bf16_t* p; ConvGeom g; int rows; int red;
-    struct Ctx { long off; bool ok; };
+    struct Ctx { int off; bool ok; };
     __device__ __forceinline__ Ctx prep(int kc0) const {
+        bool ok = kc0 < rows;
+        kc0 = ok ? kc0 : 0;
         int run = g.KW * g.C;
-        int ky = kc0 / run, off = kc0 - ky * run;
-        return {(long)ky * g.W * g.C + off, kc0 < rows};
+        int ky = fdiv(kc0, run, g.m_run), off = kc0 - ky * run;
+        return {ky * g.W * g.C + off, ok};
     }
     PDA_BF16_SOURCE_FINISH
     __device__ __forceinline__ Raw raw_at(const Ctx& c, int m, int lim, bool& ok, long poff) const {
-        ok = c.ok && m < lim;
+        ok = c.ok & (m < lim);
+        m = ok ? m : 0;
         int ohw = g.OH * g.OW;
-        int b = m / ohw, r = m - b * ohw;
-        int oy = r / g.OW, ox = r - oy * g.OW;
-        const bf16_t* base = p + (((long)b * g.H + oy * g.S) * g.W + ox * g.S) * g.C;
-        return *reinterpret_cast<const uint4*>((ok ? base + c.off : p) + poff);
+        int b = fdiv(m, ohw, g.m_ohw), r = m - b * ohw;
+        int oy = fdiv(r, g.OW, g.m_ow), ox = r - oy * g.OW;
+        int e = ((b * g.H + oy * g.S) * g.W + ox * g.S) * g.C + c.off;      // < 2^31 elements (launcher check)
+        return *reinterpret_cast<const uint4*>(p + poff + keep_if(e, ok));
     }
     PDA_SOURCE_RAW
 };
@@ -141,7 +198,15 @@ struct SrcIm2colT {     // rows = k-columns of the im2col matrix (8 consecutive)
 // ky = iy mod S (+ S a), kx = ix mod S (+ S b).  Input pixels of one parity class (py,px) all use the
 // same TH x TW = (KH/S) x (KW/S) taps, so each class is one GEMM (a problem group of the launch):
 //   rows m = (b, iy2, ix2) with iy = S*iy2 + py, ix = S*ix2 + px;   k = (a, b, o);   N = C.
-struct DgradGeom { int H, W, C, O, KH, KW, S, OH, OW, HC, WC, TH, TW, py, px; };
+struct DgradGeom { int H, W, C, O, KH, KW, S, OH, OW, HC, WC, TH, TW, py, px; unsigned m_hw, m_wc, m_o, m_tw; };
+inline DgradGeom make_dgrad_geom(const ConvGeom& cg, int O, int py, int px) {
+    DgradGeom g;
+    g.H = cg.H; g.W = cg.W; g.C = cg.C; g.O = O; g.KH = cg.KH; g.KW = cg.KW; g.S = cg.S; g.OH = cg.OH; g.OW = cg.OW;
+    g.HC = cg.H / cg.S; g.WC = cg.W / cg.S; g.TH = cg.KH / cg.S; g.TW = cg.KW / cg.S; g.py = py; g.px = px;
+    g.m_hw = fastdiv_magic(g.HC * g.WC); g.m_wc = fastdiv_magic(g.WC); g.m_o = fastdiv_magic(O);
+    g.m_tw = fastdiv_magic(g.TW);
+    return g;
+}
 
 struct SrcDgradDyK {    // A operand: element(m, k) = dy[b, iy2 - a, ix2 - b, o]  (zero outside the output grid)
     static constexpr bool kT = false;
@@ -150,18 +215,20 @@ struct SrcDgradDyK {    // A operand: element(m, k) = dy[b, iy2 - a, ix2 - b, o]
     __device__ __forceinline__ Ctx prep(int m) const {
         int hw = g.HC * g.WC;
         bool ok = m < rows;
-        int b = ok ? m / hw : 0;
+        m = ok ? m : 0;
+        int b = fdiv(m, hw, g.m_hw);
         int r = m - b * hw;
-        int iy2 = r / g.WC, ix2 = r - iy2 * g.WC;
+        int iy2 = fdiv(r, g.WC, g.m_wc), ix2 = r - iy2 * g.WC;
         return {p + (long)b * g.OH * g.OW * g.O, iy2, ix2, ok};
     }
     PDA_BF16_SOURCE_FINISH
     __device__ __forceinline__ Raw raw_at(const Ctx& c, int k, int lim, bool& ok, long poff) const {
-        int tap = k / g.O, o = k - tap * g.O;
-        int a = tap / g.TW, bb = tap - a * g.TW;
+        int tap = fdiv(k, g.O, g.m_o), o = k - tap * g.O;
+        int a = fdiv(tap, g.TW, g.m_tw), bb = tap - a * g.TW;
         int oy = c.iy2 - a, ox = c.ix2 - bb;
-        ok = c.ok && k < lim && oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW;
-        return *reinterpret_cast<const uint4*>((ok ? c.base + ((long)oy * g.OW + ox) * g.O + o : p) + poff);
+        ok = c.ok & (k < lim) & ((unsigned)oy < (unsigned)g.OH) & ((unsigned)ox < (unsigned)g.OW);
+        int e = keep_if((oy * g.OW + ox) * g.O + o, ok);
+        return *reinterpret_cast<const uint4*>(c.base + poff + e);
     }
     PDA_SOURCE_RAW
 };
@@ -170,14 +237,15 @@ struct SrcDgradWT {     // B operand: element(row = c, k = (a,b,o)) = w[o][(ky,k
     static constexpr bool kT = true;
     const bf16_t* p; DgradGeom g; int rows; int red;
     struct Ctx { const bf16_t* base; bool ok; };
-    __device__ __forceinline__ Ctx prep(int c0) const { return {p + c0, c0 < rows}; }
+    __device__ __forceinline__ Ctx prep(int c0) const { bool ok = c0 < rows; return {p + (ok ? c0 : 0), ok}; }
     PDA_BF16_SOURCE_FINISH
     __device__ __forceinline__ Raw raw_at(const Ctx& c, int k, int lim, bool& ok, long poff) const {
-        ok = c.ok && k < lim;
-        int tap = k / g.O, o = k - tap * g.O;
-        int a = tap / g.TW, bb = tap - a * g.TW;
+        ok = c.ok & (k < lim);
+        int tap = fdiv(k, g.O, g.m_o), o = k - tap * g.O;
+        int a = fdiv(tap, g.TW, g.m_tw), bb = tap - a * g.TW;
         int ky = g.py + g.S * a, kx = g.px + g.S * bb;
-        return *reinterpret_cast<const uint4*>((ok ? c.base + ((long)o * g.KH * g.KW + ky * g.KW + kx) * g.C : p) + poff);
+        int e = keep_if(o * (g.KH * g.KW * g.C) + (ky * g.KW + kx) * g.C, ok);
+        return *reinterpret_cast<const uint4*>(c.base + poff + e);
     }
     PDA_SOURCE_RAW
 };
@@ -375,8 +443,8 @@ struct EpiDgradScatter {
         for (int r = 0; r < 4; ++r) {
             int mm = m + r;
             if (mm < M) {
-                int b = mm / hw, q = mm - b * hw;
-                int iy2 = q / g.WC, ix2 = q - iy2 * g.WC;
+                int b = fdiv(mm, hw, g.m_hw), q = mm - b * hw;
+                int iy2 = fdiv(q, g.WC, g.m_wc), ix2 = q - iy2 * g.WC;
                 long pix = ((long)b * g.H + (g.S * iy2 + g.py)) * g.W + (g.S * ix2 + g.px);
                 float gr = v[r];
                 if (act != ACT_NONE) {
@@ -584,15 +652,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<SA, SB, EP>& args, int 
     // The loads of k-tiles t+1 .. t+GEMM_PF are in flight while tile t is multiplied: at batch 128 these
     // launches are a few hundred blocks of 8-16 k-tiles, i.e. bound by memory latency, not by MFMA or
     // LDS rate (counter profile: 58 % of wave cycles parked in s_waitcnt with one tile of prefetch).
-    auto tile = [&](auto slot_tag, int kk, int& buf) {
+    auto tile = [&](auto slot_tag, auto fetch_tag, int kk, int& buf) {
         constexpr int SLOT = decltype(slot_tag)::value;
         bf16_t* la = lds + buf * (A_ELEMS + B_ELEMS);
         bf16_t* lb = la + A_ELEMS;
         sa.template commit<SLOT>(la, tid);
         sb.template commit<SLOT>(lb, tid);
         __syncthreads();
-        sa.template fetch<SLOT>(G.a, kk + GEMM_PF * BK, kend);
-        sb.template fetch<SLOT>(G.b, kk + GEMM_PF * BK, kend);
+        if constexpr (decltype(fetch_tag)::value) {
+            sa.template fetch<SLOT>(G.a, kk + GEMM_PF * BK, kend);
+            sb.template fetch<SLOT>(G.b, kk + GEMM_PF * BK, kend);
+        }
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 fa[FM], fb[FN];
@@ -621,16 +691,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<SA, SB, EP>& args, int 
     sb.template fetch<1>(G.b, kbeg + BK, kend);
     sa.template fetch<2>(G.a, kbeg + 2 * BK, kend);
     sb.template fetch<2>(G.b, kbeg + 2 * BK, kend);
-    int buf = 0;
-    for (int k0 = kbeg;;) {             // straight-line body, exits only by break: no merges inside the ring
-        tile(std::integral_constant<int, 0>{}, k0, buf);
-        if (k0 + BK >= kend) break;
-        tile(std::integral_constant<int, 1>{}, k0 + BK, buf);
-        if (k0 + 2 * BK >= kend) break;
-        tile(std::integral_constant<int, 2>{}, k0 + 2 * BK, buf);
-        k0 += GEMM_PF * BK;
-        if (k0 >= kend) break;
-    }
+    GEMM_RING_LOOP
 
     // C/D layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
     const EP ep = epi_for_slice(G.e, args.ksplit > 0 ? by : 0);
@@ -711,7 +772,7 @@ __device__ __forceinline__ void gemm_body_x3(const GemmArgs<SA, SB, EP>& args, i
         if (LA) sal.template fetch<SLOT>(al, kk, kend);
         if (LB) sbl.template fetch<SLOT>(bl, kk, kend);
     };
-    auto tile = [&](auto slot_tag, int kk, int& buf) {
+    auto tile = [&](auto slot_tag, auto fetch_tag, int kk, int& buf) {
         constexpr int SLOT = decltype(slot_tag)::value;
         bf16_t* lah = lds + buf * BUF;
         bf16_t* lal = lah + A_ELEMS;
@@ -722,7 +783,7 @@ __device__ __forceinline__ void gemm_body_x3(const GemmArgs<SA, SB, EP>& args, i
         if (LA) sal.template commit<SLOT>(lal, tid);
         if (LB) sbl.template commit<SLOT>(lbl, tid);
         __syncthreads();
-        fetch_all(slot_tag, kk + GEMM_PF * BK);
+        if constexpr (decltype(fetch_tag)::value) fetch_all(slot_tag, kk + GEMM_PF * BK);
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 fah[FM], fal[FM], fbh[FN], fbl[FN];
@@ -756,16 +817,7 @@ __device__ __forceinline__ void gemm_body_x3(const GemmArgs<SA, SB, EP>& args, i
     fetch_all(std::integral_constant<int, 0>{}, kbeg);
     fetch_all(std::integral_constant<int, 1>{}, kbeg + BK);
     fetch_all(std::integral_constant<int, 2>{}, kbeg + 2 * BK);
-    int buf = 0;
-    for (int k0 = kbeg;;) {
-        tile(std::integral_constant<int, 0>{}, k0, buf);
-        if (k0 + BK >= kend) break;
-        tile(std::integral_constant<int, 1>{}, k0 + BK, buf);
-        if (k0 + 2 * BK >= kend) break;
-        tile(std::integral_constant<int, 2>{}, k0 + 2 * BK, buf);
-        k0 += GEMM_PF * BK;
-        if (k0 >= kend) break;
-    }
+    GEMM_RING_LOOP
 
     const EP ep = epi_for_slice(G.e, args.ksplit > 0 ? by : 0);
 #pragma unroll

@@ -9,14 +9,6 @@
 
 namespace {
 
-ConvGeom make_geom(int H, int W, int C, int KH, int KW, int S) {
-    ConvGeom g;
-    g.H = H; g.W = W; g.C = C; g.KH = KH; g.KW = KW; g.S = S;
-    g.OH = (H - KH) / S + 1;
-    g.OW = (W - KW) / S + 1;
-    return g;
-}
-
 // fewer 64x64 tiles than CUs on the chip: halve the tile so that twice the workgroups share the work
 bool small_grid(int M, int N, int groups) {
     long tiles = (long)((M + 63) / 64) * ((N + 63) / 64) * groups;
@@ -145,9 +137,7 @@ PDA_EXPORT void pda_conv_dgrad(const void* dy, const void* w, const void* yin, v
     int K = (KH / S) * (KW / S) * O;
     for (int py = 0; py < S; ++py)
         for (int px = 0; px < S; ++px) {
-            DgradGeom g;
-            g.H = H; g.W = W; g.C = C; g.O = O; g.KH = KH; g.KW = KW; g.S = S; g.OH = cg.OH; g.OW = cg.OW;
-            g.HC = H / S; g.WC = W / S; g.TH = KH / S; g.TW = KW / S; g.py = py; g.px = px;
+            DgradGeom g = make_dgrad_geom(cg, O, py, px);
             int M = batch * g.HC * g.WC;
             a.g[ng].a = {(const bf16_t*)dy, g, M, K};
             a.g[ng].b = {(const bf16_t*)w, g, C, K};
