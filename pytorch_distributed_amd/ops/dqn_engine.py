@@ -271,13 +271,22 @@ def cnn_forward(geom, nets, frames, idxs, acts, B, norm_val, keep_first_only=Tru
     Leaves fc1's pre-activation split-K sums in acts.h1pre[g] (which must be zero)."""
     g, n = geom, len(nets)
     if getattr(acts, "split", False):
-        # fp32-precision learner: layer-wise implicit GEMMs on split-bf16 planes (csrc/gemm_x3.hip)
-        nn.x3_conv_fwd_u8(frames, idxs, [w.w[0] for w in nets], [w.b[0] for w in nets], acts.a1[:n], B,
-                          g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / float(norm_val))
-        nn.x3_conv_fwd(acts.a1[:n], [w.w[1] for w in nets], [w.b[1] for w in nets], acts.a2[:n], B, g.H1, g.W1, 32,
-                       4, 4, 2, 64)
-        nn.x3_conv_fwd(acts.a2[:n], [w.w[2] for w in nets], [w.b[2] for w in nets], acts.a3[:n], B, g.H2, g.W2, 64,
-                       3, 3, 1, 64)
+        if nn.x3_cnn_fwd_stack_supported(g.H, g.W, g.C):
+            # one launch, one workgroup per image and network, a1 / a2 (both planes) LDS-resident
+            keep = [True] + [False] * (n - 1) if keep_first_only else [True] * n
+            nn.x3_cnn_fwd_stack(frames, idxs, [w.w[0] for w in nets], [w.b[0] for w in nets],
+                                [w.w[1] for w in nets], [w.b[1] for w in nets], [w.w[2] for w in nets],
+                                [w.b[2] for w in nets], [acts.a1[i] if keep[i] else None for i in range(n)],
+                                [acts.a2[i] if keep[i] else None for i in range(n)], acts.a3[:n], B, g.H, g.W, g.C,
+                                1.0 / float(norm_val))
+        else:
+            # layer-wise implicit GEMMs on split-bf16 planes (csrc/gemm_x3.hip)
+            nn.x3_conv_fwd_u8(frames, idxs, [w.w[0] for w in nets], [w.b[0] for w in nets], acts.a1[:n], B,
+                              g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / float(norm_val))
+            nn.x3_conv_fwd(acts.a1[:n], [w.w[1] for w in nets], [w.b[1] for w in nets], acts.a2[:n], B, g.H1, g.W1,
+                           32, 4, 4, 2, 64)
+            nn.x3_conv_fwd(acts.a2[:n], [w.w[2] for w in nets], [w.b[2] for w in nets], acts.a3[:n], B, g.H2, g.W2,
+                           64, 3, 3, 1, 64)
         if acts.h1_slices:
             nn.x3_linear_fwd(acts.a3[:n], [w.w[3] for w in nets], acts.h1pre[:n], B, g.HID, g.F, g.F, g.F, g.HID,
                              ksplit=acts.h1_ksplit, slice_stride=B * g.HID)

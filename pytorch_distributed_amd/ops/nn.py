@@ -457,6 +457,9 @@ def _X():
         L.pda_x3_conv_wgrad.argtypes = [_vp] * 6 + [c_int, c_int] + [_vp] * 6 + [c_int, _vp, _vp, c_int, _vp]
         L.pda_x3_conv_wgrad_u8.argtypes = ([_vp, c_long, _vp, _vp, _vp, _vp] + [c_int] * 8 +
                                            [c_float, c_long, c_long, c_int, _vp])
+        L.pda_cnn_fwd_stack_x3.argtypes = ([_vp] * 8 + [c_long, _vp, c_long, _vp, c_long, _vp, c_long] + [c_int] * 5 +
+                                           [c_float, _vp])
+        L.pda_cnn_fwd_stack_x3.restype = None
         for name in ("pda_x3_conv_fwd_u8", "pda_x3_conv_fwd", "pda_x3_linear_fwd", "pda_x3_linear_dgrad",
                      "pda_x3_conv_dgrad", "pda_x3_linear_wgrad2", "pda_x3_fc_backward_duo", "pda_x3_conv_wgrad",
                      "pda_x3_conv_wgrad_u8"):
@@ -484,6 +487,25 @@ def x3_conv_fwd_u8(frames, idx, w, bias, out, batch, H, W, C, KH, KW, S, O, scal
     assert KW == 8 and len(frames) <= GEMM_MAX_GROUPS and (C * KH * KW) % 8 == 0
     _X().pda_x3_conv_fwd_u8(_arr(frames), _arr(idx), _arr(w), _same_plane(w), _arr(bias), _arr(out), _same_plane(out),
                             len(frames), batch, H, W, C, KH, KW, S, O, float(scale), act, _stream())
+
+
+def x3_cnn_fwd_stack_supported(H, W, C):
+    """True when the one-launch fp32-precision conv stack (cnn_fwd_stack_x3_kernel) covers this input."""
+    import os
+    return os.environ.get("PDA_X3_FUSED_FWD", "1") != "0" and cnn_fwd_stack_supported(H, W, C)
+
+
+def x3_cnn_fwd_stack(frames, idx, w1, b1, w2, b2, w3, b3, a1, a2, a3, batch, H, W, C, scale):
+    """cnn_fwd_stack on split planes: weights (all of one network's shadow buffer: one plane offset) and activations
+    as Planes; a1 / a2 entries may be None."""
+    n = len(frames)
+    assert n <= GEMM_MAX_GROUPS and H == 84 and W == 84 and C == 4
+    wp = _same_plane(list(w1) + list(w2) + list(w3))
+    kept1, kept2 = [t for t in a1 if t is not None], [t for t in a2 if t is not None]
+    _X().pda_cnn_fwd_stack_x3(_arr(frames), _arr(idx), _arr(w1), _arr(b1), _arr(w2), _arr(b2), _arr(w3), _arr(b3), wp,
+                              _arr(a1), _same_plane(kept1) if kept1 else 0, _arr(a2),
+                              _same_plane(kept2) if kept2 else 0, _arr(a3), _same_plane(a3), n, batch, H, W, C,
+                              float(scale), _stream())
 
 
 def x3_conv_fwd(x, w, bias, out, batch, H, W, C, KH, KW, S, O, act=ACT_RELU):

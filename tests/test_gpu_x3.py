@@ -66,6 +66,58 @@ def test_x3_conv1_fwd_u8(nn, batch, use_idx):
     assert rel(from_nhwc(out.value(), batch, 20, 20, 32), ref) < TOL
 
 
+class _View(object):
+    """hi-plane view of a shared split buffer + the offset to its lo plane (what nn.x3_* take as an operand)."""
+
+    def __init__(self, hi, plane):
+        self.hi, self.plane = hi, plane
+
+    def data_ptr(self):
+        return self.hi.data_ptr()
+
+
+@pytest.mark.parametrize("batch,use_idx", [(9, True), (3, False)])
+def test_x3_cnn_fwd_stack(nn, batch, use_idx):
+    """conv1 -> conv2 -> conv3 in one launch on split planes (cnn_fwd_stack_x3_kernel), two networks, the second
+    without kept a1 / a2, against fp64 torch."""
+    if not nn.x3_cnn_fwd_stack_supported(84, 84, 4):
+        pytest.skip("fused fp32-precision forward switched off")
+    torch.manual_seed(5)
+    mem = torch.randint(0, 256, (32, 4, 84, 84), dtype=torch.uint8, device="cuda")
+    idx = torch.randint(0, 32, (batch,), dtype=torch.int32, device="cuda") if use_idx else None
+    nets = []
+    for n in range(2):
+        ws = [torch.randn(32, 4, 8, 8, device="cuda") / 16, torch.randn(64, 32, 4, 4, device="cuda") / 22,
+              torch.randn(64, 64, 3, 3, device="cuda") / 24]
+        bs = [torch.randn(32, device="cuda") / 4, torch.randn(64, device="cuda") / 4, torch.randn(64, device="cuda") / 4]
+        flat = [ws[0].reshape(32, -1), ws[1].permute(0, 2, 3, 1).reshape(64, -1), ws[2].permute(0, 2, 3, 1).reshape(64, -1)]
+        total = sum(f.numel() for f in flat)
+        buf = torch.zeros(2, total, dtype=torch.bfloat16, device="cuda")       # one shadow buffer: one plane offset
+        views, off = [], 0
+        for f in flat:
+            hi = f.contiguous().to(torch.bfloat16)
+            buf[0, off:off + f.numel()] = hi.reshape(-1)
+            buf[1, off:off + f.numel()] = (f.contiguous() - hi.float()).to(torch.bfloat16).reshape(-1)
+            views.append(_View(buf[0, off:off + f.numel()].view(f.shape), total))
+            off += f.numel()
+        nets.append((ws, bs, views, buf))
+    a1 = [nn.Planes(batch * 400, 32, device="cuda"), None]
+    a2 = [nn.Planes(batch * 81, 64, device="cuda"), None]
+    a3 = [nn.Planes(batch * 49, 64, device="cuda") for _ in range(2)]
+    nn.x3_cnn_fwd_stack([mem, mem], [idx, idx], [n[2][0] for n in nets], [n[1][0] for n in nets],
+                        [n[2][1] for n in nets], [n[1][1] for n in nets], [n[2][2] for n in nets],
+                        [n[1][2] for n in nets], a1, a2, a3, batch, 84, 84, 4, 1.0 / 255.0)
+    x = (mem[idx.long()] if use_idx else mem[:batch]).double() / 255.0
+    for n, (ws, bs, _, _) in enumerate(nets):
+        r1 = F.relu(F.conv2d(x, ws[0].double(), bs[0].double(), stride=4))
+        r2 = F.relu(F.conv2d(r1, ws[1].double(), bs[1].double(), stride=2))
+        r3 = F.relu(F.conv2d(r2, ws[2].double(), bs[2].double(), stride=1))
+        if n == 0:
+            assert rel(from_nhwc(a1[0].value(), batch, 20, 20, 32), r1) < TOL
+            assert rel(from_nhwc(a2[0].value(), batch, 9, 9, 64), r2) < TOL
+        assert rel(from_nhwc(a3[n].value(), batch, 7, 7, 64), r3) < TOL
+
+
 @pytest.mark.parametrize("geom", [(20, 20, 32, 4, 4, 2, 64), (9, 9, 64, 3, 3, 1, 64)])
 def test_x3_conv_fwd_and_backward(nn, geom):
     H, W, C, KH, KW, S, O = geom
