@@ -1361,6 +1361,298 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
     }
 }
 
+// ---- the data-gradient chain at fp32 precision (split-bf16 planes) ---------------------------------------
+// da3 / da2 / da1 are (hi, lo) pairs of planes, the weights too; the forward activations only gate (relu'), so
+// their hi planes suffice.  Same per-image LDS data flow as cnn_dgrad_stack_kernel with a second grid / row set
+// for every lo plane (148 KB), one image per workgroup, products w_hi d_hi + w_lo d_hi + w_hi d_lo in three
+// accumulation chains.  All four weight-fragment sets (272 registers) are staged through LDS at the start, under
+// the input loads; conv3^T fetches its da3 fragments in thirds of the reduction to stay inside the register file.
+#define DX_A1L (400 * D1_CP)                    // da1 lo rows (a1 hi / da1 hi rows sit at 0)
+#define DX_A2H (2 * 400 * D1_CP)                // a2 hi -> da2 hi grid
+#define DX_A2L (DX_A2H + 11 * D2_RP)            // da2 lo grid
+#define DX_D3H (DX_A2L + 11 * D2_RP)            // da3 hi grid
+#define DX_D3L (DX_D3H + 11 * D3_RP)            // da3 lo grid
+#define DX_LDS_ELEMS (DX_D3L + 11 * D3_RP)
+
+struct DgradStackX3Args {
+    const bf16_t* da3; const bf16_t* a2; const bf16_t* a1; const bf16_t* w3; const bf16_t* w2;
+    bf16_t* da2; bf16_t* da1; int batch;
+    long da3_plane, w_plane, da2_plane, da1_plane;
+};
+
+// (hi, lo) planes of 4 gradient values, gated by relu'(act): 8 bytes each
+__device__ __forceinline__ void gate_split4(uint2 act, f32x4 v, uint2& hi, uint2& lo) {
+    const uint2 h = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+    const float r0 = v[0] - bf2f((bf16_t)(h.x & 0xffffu)), r1 = v[1] - bf2f((bf16_t)(h.x >> 16));
+    const float r2 = v[2] - bf2f((bf16_t)(h.y & 0xffffu)), r3 = v[3] - bf2f((bf16_t)(h.y >> 16));
+    hi = make_uint2(relu_gate2(act.x, h.x), relu_gate2(act.y, h.y));
+    lo = make_uint2(relu_gate2(act.x, pack2bf(r0, r1)), relu_gate2(act.y, pack2bf(r2, r3)));
+}
+
+__global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Args a) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    constexpr int P1 = 400, P2 = 81, P3 = 49, NRB3 = 6, NRB2 = 7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const int img = blockIdx.x;
+
+    // ---- both planes of both weight tensors and this image's inputs (a1 / a2: hi planes only): in flight together
+    u32x4 i1[7], i2[3], i3h[2], i3l[2];
+    bf16x8 wf3h[18], wf3l[18];      // conv3^T: this wave's 16 input channels; k-step = (tap, o half)
+    bf16x8 wf2h[8][2], wf2l[8][2];  // conv2^T: this wave's parity class; (tap a,b ; o half) x 2 channel blocks
+    const int py = wave >> 1, px = wave & 1;
+    {
+        u32x4 r3h[18], r3l[18], r2h[16], r2l[16];
+        // chunk i of a thread: w3 (tap = i / 2, o = tid / 8 + 32 (i % 2), rg = tid % 8), w2 (tap = i, o = tid / 4,
+        // rg = tid % 4) -- constant offsets from one per-lane base, so the 68 loads share a few address registers
+        const bf16_t* p3 = a.w3 + (long)(tid >> 3) * 576 + (tid & 7) * 8;
+        const bf16_t* p2 = a.w2 + (long)(tid >> 2) * 512 + (tid & 3) * 8;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            r3h[i] = *reinterpret_cast<const u32x4*>(p3 + (i & 1) * 32 * 576 + (i >> 1) * 64);
+            r3l[i] = *reinterpret_cast<const u32x4*>(p3 + a.w_plane + (i & 1) * 32 * 576 + (i >> 1) * 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            r2h[i] = *reinterpret_cast<const u32x4*>(p2 + i * 32);
+            r2l[i] = *reinterpret_cast<const u32x4*>(p2 + a.w_plane + i * 32);
+        }
+        const int o3 = tid >> 3, rg3 = tid & 7, o2 = tid >> 2, rg2 = tid & 3;
+        const int l3a = o3 * 64 + (((2 * rg3) ^ swz_t<64>(o3)) << 2);
+        const int l3b = (o3 + 32) * 64 + (((2 * rg3) ^ swz_t<64>(o3 + 32)) << 2);
+        const int l2 = o2 * 32 + (((2 * rg2) ^ swz_t<32>(o2)) << 2);
+        auto stage3 = [&](const u32x4 (&r)[18], bf16x8 (&wf)[18]) {
+#pragma unroll
+            for (int i = 0; i < 18; ++i)
+                *reinterpret_cast<u32x4*>(lds + (i >> 1) * 4096 + ((i & 1) ? l3b : l3a)) = r[i];
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 18; ++ks) wf[ks] = read_frag<true, 64, 32>(lds + (ks >> 1) * 4096, wave * 16, ks & 1, lane);
+            __syncthreads();
+        };
+        auto stage2 = [&](const u32x4 (&r)[16], bf16x8 (&wf)[8][2]) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) *reinterpret_cast<u32x4*>(lds + i * 2048 + l2) = r[i];
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {       // t = (a * 2 + b) * 2 + half
+                int ta = t >> 2, tb = (t >> 1) & 1, half = t & 1;
+                int tap = (py + 2 * ta) * 4 + (px + 2 * tb);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) wf[t][nb] = read_frag<true, 32, 32>(lds + tap * 2048, nb * 16, half, lane);
+            }
+            __syncthreads();
+        };
+        stage3(r3h, wf3h);
+        {   // this image's inputs go out behind the first weight plane (they are consumed after the staging)
+            const u32x4* s1 = reinterpret_cast<const u32x4*>(a.a1 + (long)img * 400 * 32);
+            const u32x4* s2 = reinterpret_cast<const u32x4*>(a.a2 + (long)img * 81 * 64);
+            const u32x4* s3 = reinterpret_cast<const u32x4*>(a.da3 + (long)img * 49 * 64);
+            const u32x4* s3l = reinterpret_cast<const u32x4*>(a.da3 + a.da3_plane + (long)img * 49 * 64);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { int t = tid + i * 256; i1[i] = s1[t < 1600 ? t : 0]; }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { int t = tid + i * 256; i2[i] = s2[t < 648 ? t : 0]; }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { int t = tid + i * 256; i3h[i] = s3[t < 392 ? t : 0]; i3l[i] = s3l[t < 392 ? t : 0]; }
+        }
+        stage3(r3l, wf3l);
+        stage2(r2h, wf2h);
+        stage2(r2l, wf2l);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks) { pin_agpr(wf3h[ks]); pin_agpr(wf3l[ks]); }
+    // the four grids start out all zero; the image only writes their interiors
+    for (int t = tid; t < (DX_LDS_ELEMS - DX_A2H) / 8; t += 256)
+        *reinterpret_cast<uint4*>(lds + DX_A2H + t * 8) = make_uint4(0, 0, 0, 0);
+
+    int in1[7], in2[3], in3[2];
+    int ld3[NRB3], st3[NRB3], ld2[NRB2], st2[NRB2];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        int t = tid + i * 256;
+        t = t < P1 * 4 ? t : 0;
+        in1[i] = (t >> 2) * D1_CP + (t & 3) * 8;
+        asm volatile("" : "+v"(in1[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int t = tid + i * 256;
+        t = t < P2 * 8 ? t : 0;
+        int pix = t >> 3, y = pix / 9, x = pix - 9 * y;
+        in2[i] = DX_A2H + (y + 1) * D2_RP + (x + 1) * D2_CP + (t & 7) * 8;
+        asm volatile("" : "+v"(in2[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int t = tid + i * 256;
+        t = t < P3 * 8 ? t : 0;
+        int pix = t >> 3, y = pix / 7, x = pix - 7 * y;
+        in3[i] = DX_D3H + (y + 2) * D3_RP + (x + 2) * D3_CP + (t & 7) * 8;
+        asm volatile("" : "+v"(in3[i]));
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB3; ++rb) {
+        int m = rb * 16 + l15;
+        m = m < P2 ? m : 0;
+        int iy = m / 9, ix = m - 9 * iy;
+        ld3[rb] = DX_D3H + (iy + 2) * D3_RP + (ix + 2) * D3_CP + g4 * 8;
+        st3[rb] = DX_A2H + (iy + 1) * D2_RP + (ix + 1) * D2_CP + wave * 16 + 4 * g4;
+        asm volatile("" : "+v"(ld3[rb]), "+v"(st3[rb]));
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB2; ++rb) {
+        int q = rb * 16 + l15;
+        q = q < 100 ? q : 0;
+        int iy2 = q / 10, ix2 = q - 10 * iy2;
+        ld2[rb] = DX_A2H + (iy2 + 1) * D2_RP + (ix2 + 1) * D2_CP + g4 * 8;
+        st2[rb] = ((2 * iy2 + py) * 20 + 2 * ix2 + px) * D1_CP + 4 * g4;
+        asm volatile("" : "+v"(ld2[rb]), "+v"(st2[rb]));
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                    // grids zeroed
+#pragma unroll
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(lds + in1[i]) = i1[i];
+    if (tid < P1 * 4 - 1536) *reinterpret_cast<u32x4*>(lds + in1[6]) = i1[6];
+    *reinterpret_cast<u32x4*>(lds + in2[0]) = i2[0];
+    *reinterpret_cast<u32x4*>(lds + in2[1]) = i2[1];
+    if (tid < P2 * 8 - 512) *reinterpret_cast<u32x4*>(lds + in2[2]) = i2[2];
+    *reinterpret_cast<u32x4*>(lds + in3[0]) = i3h[0];
+    *reinterpret_cast<u32x4*>(lds + in3[0] + (DX_D3L - DX_D3H)) = i3l[0];
+    if (tid < P3 * 8 - 256) {
+        *reinterpret_cast<u32x4*>(lds + in3[1]) = i3h[1];
+        *reinterpret_cast<u32x4*>(lds + in3[1] + (DX_D3L - DX_D3H)) = i3l[1];
+    }
+    __syncthreads();
+
+    // ---- conv3^T: da2[(iy,ix)][c] = sum_{tap,o} w3[o][tap][c] da3[(iy-ky, ix-kx)][o], times relu'(a2); a unit is a
+    // third (6 k-steps) of a row block's reduction
+    {
+        auto load = [&](bf16x8 (&xh)[6], bf16x8 (&xl)[6], int rb, int third) {
+            const bf16_t* base = lds + ld3[rb];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int ks = 6 * third + j, tap = ks >> 1, ky = tap / 3, kx = tap - 3 * ky;
+                const bf16_t* q = base - ky * D3_RP - kx * D3_CP + (ks & 1) * 32;
+                xh[j] = *reinterpret_cast<const bf16x8*>(q);
+                xl[j] = *reinterpret_cast<const bf16x8*>(q + (DX_D3L - DX_D3H));
+            }
+        };
+        auto mul = [&](const bf16x8 (&xh)[6], const bf16x8 (&xl)[6], int third, f32x4 (&c)[3]) {
+            if (third == 0) { c[0] = zero4; c[1] = zero4; c[2] = zero4; }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                c[0] = mfma_wx(wf3h[6 * third + j], xh[j], c[0]);
+                c[1] = mfma_wx(wf3l[6 * third + j], xh[j], c[1]);
+                c[2] = mfma_wx(wf3h[6 * third + j], xl[j], c[2]);
+            }
+        };
+        auto store = [&](const f32x4 (&c)[3], int rb) {
+            if (rb * 16 + l15 < P2) {
+                uint2* cell = reinterpret_cast<uint2*>(lds + st3[rb]);      // this wave's channels only
+                uint2 h, l;
+                gate_split4(*cell, c[0] + (c[1] + c[2]), h, l);
+                *cell = h;
+                *reinterpret_cast<uint2*>(lds + st3[rb] + (DX_A2L - DX_A2H)) = l;
+            }
+        };
+        bf16x8 xah[6], xal[6], xbh[6], xbl[6];
+        f32x4 ca[3], cb[3];
+        load(xah, xal, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 3 * NRB3; ++u) {
+            const int rb = u / 3, third = u - 3 * rb;
+            if (u + 1 < 3 * NRB3) {
+                if (u & 1) load(xah, xal, (u + 1) / 3, (u + 1) % 3); else load(xbh, xbl, (u + 1) / 3, (u + 1) % 3);
+            }
+            if (u & 1) { if (rb & 1) mul(xbh, xbl, third, cb); else mul(xbh, xbl, third, ca); }
+            else { if (rb & 1) mul(xah, xal, third, cb); else mul(xah, xal, third, ca); }
+            if (third == 0 && rb > 0) { if (rb & 1) store(ca, rb - 1); else store(cb, rb - 1); }
+            STACK_SCHED(18, 2, 3, 3)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if ((NRB3 - 1) & 1) store(cb, NRB3 - 1); else store(ca, NRB3 - 1);
+    }
+    __syncthreads();                    // the a2 grids now hold da2 (hi, lo)
+    {
+        uint4* dst = reinterpret_cast<uint4*>(a.da2 + (long)img * P2 * 64);
+        uint4* dstl = reinterpret_cast<uint4*>(a.da2 + a.da2_plane + (long)img * P2 * 64);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (i < 2 || tid < P2 * 8 - 512) {
+                dst[tid + i * 256] = *reinterpret_cast<const uint4*>(lds + in2[i]);
+                dstl[tid + i * 256] = *reinterpret_cast<const uint4*>(lds + in2[i] + (DX_A2L - DX_A2H));
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { pin_agpr(wf2h[t][0]); pin_agpr(wf2h[t][1]); pin_agpr(wf2l[t][0]); pin_agpr(wf2l[t][1]); }
+    // ---- conv2^T for this wave's parity class: input pixel (2 iy2 + py, 2 ix2 + px), taps (py + 2a, px + 2b)
+    {
+        auto load = [&](bf16x8 (&xh)[8], bf16x8 (&xl)[8], int rb) {
+            const bf16_t* base = lds + ld2[rb];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16_t* q = base - (t >> 1) * D2_RP - (t & 1) * D2_CP;
+                xh[2 * t] = *reinterpret_cast<const bf16x8*>(q);
+                xh[2 * t + 1] = *reinterpret_cast<const bf16x8*>(q + 32);
+                xl[2 * t] = *reinterpret_cast<const bf16x8*>(q + (DX_A2L - DX_A2H));
+                xl[2 * t + 1] = *reinterpret_cast<const bf16x8*>(q + (DX_A2L - DX_A2H) + 32);
+            }
+        };
+        auto mul = [&](const bf16x8 (&xh)[8], const bf16x8 (&xl)[8], f32x4 (&c0)[3], f32x4 (&c1)[3]) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { c0[i] = zero4; c1[i] = zero4; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                c0[0] = mfma_wx(wf2h[t][0], xh[t], c0[0]);
+                c1[0] = mfma_wx(wf2h[t][1], xh[t], c1[0]);
+                c0[1] = mfma_wx(wf2l[t][0], xh[t], c0[1]);
+                c1[1] = mfma_wx(wf2l[t][1], xh[t], c1[1]);
+                c0[2] = mfma_wx(wf2h[t][0], xl[t], c0[2]);
+                c1[2] = mfma_wx(wf2h[t][1], xl[t], c1[2]);
+            }
+        };
+        auto store = [&](const f32x4 (&c0)[3], const f32x4 (&c1)[3], int rb) {
+            if (rb * 16 + l15 < 100) {
+                uint2* cell = reinterpret_cast<uint2*>(lds + st2[rb]);      // this class's pixels only
+                uint2* celll = reinterpret_cast<uint2*>(lds + st2[rb] + DX_A1L);
+                uint2 h, l;
+                gate_split4(cell[0], c0[0] + (c0[1] + c0[2]), h, l);
+                cell[0] = h; celll[0] = l;
+                gate_split4(cell[4], c1[0] + (c1[1] + c1[2]), h, l);        // + 16 channels
+                cell[4] = h; celll[4] = l;
+            }
+        };
+        bf16x8 xah[8], xal[8], xbh[8], xbl[8];
+        f32x4 ca0[3], ca1[3], cb0[3], cb1[3];
+        load(xah, xal, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rb = 0; rb < NRB2; ++rb) {
+            if (rb + 1 < NRB2) { if (rb & 1) load(xah, xal, rb + 1); else load(xbh, xbl, rb + 1); }
+            if (rb & 1) mul(xbh, xbl, cb0, cb1); else mul(xah, xal, ca0, ca1);
+            if (rb > 0) { if (rb & 1) store(ca0, ca1, rb - 1); else store(cb0, cb1, rb - 1); }
+            STACK_SCHED(48, 1, 3, 2)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if ((NRB2 - 1) & 1) store(cb0, cb1, NRB2 - 1); else store(ca0, ca1, NRB2 - 1);
+    }
+    __syncthreads();                    // the a1 rows now hold da1 (hi), the rows behind them its lo plane
+    {
+        uint4* dst = reinterpret_cast<uint4*>(a.da1 + (long)img * P1 * 32);
+        uint4* dstl = reinterpret_cast<uint4*>(a.da1 + a.da1_plane + (long)img * P1 * 32);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            if (i < 6 || tid < P1 * 4 - 1536) {
+                dst[tid + i * 256] = *reinterpret_cast<const uint4*>(lds + in1[i]);
+                dstl[tid + i * 256] = *reinterpret_cast<const uint4*>(lds + in1[i] + DX_A1L);
+            }
+        }
+    }
+}
+
 // ---- conv2 + conv3 weight gradients per image (large batches) -------------------------------------------
 // dW2[o][(tap,c)] = sum_pix da2[pix][o] a1[(2 oy + ky, 2 ox + kx)][c],  dW3 likewise from da3 and a2.
 // As implicit GEMMs over all images these two are the most expensive launches of a batch-4096 step (2 x 133
@@ -1740,6 +2032,22 @@ PDA_EXPORT void pda_cnn_dgrad_stack(const void* da3, const void* a2, const void*
     DgradStackArgs a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3,
                         (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch, nullptr, nullptr, nullptr, nullptr, 0, 0, 1.f};
     launch_dgrad_stack(a, stream);
+}
+
+// the chain at fp32 precision: da3 / da2 / da1 and the weights as (hi, lo) planes, a2 / a1 hi planes (relu masks)
+PDA_EXPORT void pda_cnn_dgrad_stack_x3(const void* da3, long da3_plane, const void* a2, const void* a1,
+                                       const void* w3, const void* w2, long w_plane, void* da2, long da2_plane,
+                                       void* da1, long da1_plane, int batch, hipStream_t stream) {
+    DgradStackX3Args a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3,
+                          (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch, da3_plane, w_plane, da2_plane, da1_plane};
+    static_assert(DX_LDS_ELEMS >= 9 * 4096 && DX_LDS_ELEMS * 2 <= 160 * 1024, "weight staging / LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_x3_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(cnn_dgrad_stack_x3_kernel, dim3(batch), dim3(256), (size_t)DX_LDS_ELEMS * 2, stream, a);
 }
 
 // same, plus conv1's weight gradient from uint8 frames (slab slice per workgroup: pda_cnn_dgrad_stack_slices(batch))

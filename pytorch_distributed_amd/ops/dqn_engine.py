@@ -564,8 +564,12 @@ class DqnCnnEngine(object):
             if not self.fc_duo:
                 nn.x3_linear_dgrad(a.dh1, on.w[3], a.a3[0].hi, a.da3, B, g.HID, g.F, g.HID, g.F, g.F, g.F,
                                    act=nn.ACT_RELU)
-            nn.x3_conv_dgrad(a.da3, on.w[2], a.a2[0].hi, a.da2, B, g.H2, g.W2, 64, 3, 3, 1, 64, act=nn.ACT_RELU)
-            nn.x3_conv_dgrad(a.da2, on.w[1], a.a1[0].hi, a.da1, B, g.H1, g.W1, 32, 4, 4, 2, 64, act=nn.ACT_RELU)
+            if nn.x3_cnn_dgrad_stack_supported(g.H, g.W, g.C):
+                # both conv data gradients in one launch (per image, every plane LDS-resident)
+                nn.x3_cnn_dgrad_stack(a.da3, a.a2[0].hi, a.a1[0].hi, on.w[2], on.w[1], a.da2, a.da1, B)
+            else:
+                nn.x3_conv_dgrad(a.da3, on.w[2], a.a2[0].hi, a.da2, B, g.H2, g.W2, 64, 3, 3, 1, 64, act=nn.ACT_RELU)
+                nn.x3_conv_dgrad(a.da2, on.w[1], a.a1[0].hi, a.da1, B, g.H1, g.W1, 32, 4, 4, 2, 64, act=nn.ACT_RELU)
             geoms = [(g.H1, g.W1, 32, 4, 4, 2), (g.H2, g.W2, 64, 3, 3, 1)]
             if self.pair_wgrad:
                 assert ks2 == ks3

@@ -157,6 +157,46 @@ def test_x3_conv_fwd_and_backward(nn, geom):
     assert rel(from_nhwc(dx.value(), batch, H, W, C), xd.grad * (xd.detach() > 0)) < TOL
 
 
+@pytest.mark.parametrize("batch", [7, 130])
+def test_x3_cnn_dgrad_stack(nn, batch):
+    """da3 -> da2 -> da1 in one launch on split planes (cnn_dgrad_stack_x3_kernel) against fp64 torch autograd of
+    relu(conv3(relu(conv2(a1)))) with random a1 >= 0 (about half of it exactly 0: the relu' gate of the last stage)."""
+    if not nn.x3_cnn_dgrad_stack_supported(84, 84, 4):
+        pytest.skip("fused fp32-precision backward switched off")
+    torch.manual_seed(11)
+    a1 = torch.relu(torch.randn(batch, 32, 20, 20, device="cuda"))
+    w2 = torch.randn(64, 32, 4, 4, device="cuda") / 22
+    w3 = torch.randn(64, 64, 3, 3, device="cuda") / 24
+    b2, b3 = torch.randn(64, device="cuda") / 4, torch.randn(64, device="cuda") / 4
+    da3 = torch.randn(batch, 64, 7, 7, device="cuda")
+    a1d = a1.double().requires_grad_(True)
+    a2d = F.relu(F.conv2d(a1d, w2.double(), b2.double(), stride=2))
+    a2d.retain_grad()
+    pre3 = F.conv2d(a2d, w3.double(), b3.double(), stride=1)
+    pre3.backward(da3.double())
+    ref_da2 = a2d.grad * (a2d.detach() > 0)         # gradient w.r.t. conv2's pre-activation
+    ref_da1 = a1d.grad * (a1d.detach() > 0)         # ... conv1's pre-activation
+    flat = [w2.permute(0, 2, 3, 1).reshape(64, -1).contiguous(), w3.permute(0, 2, 3, 1).reshape(64, -1).contiguous()]
+    total = sum(f.numel() for f in flat)
+    buf = torch.zeros(2, total, dtype=torch.bfloat16, device="cuda")
+    views, off = [], 0
+    for f in flat:
+        hi = f.to(torch.bfloat16)
+        buf[0, off:off + f.numel()] = hi.reshape(-1)
+        buf[1, off:off + f.numel()] = (f - hi.float()).to(torch.bfloat16).reshape(-1)
+        views.append(_View(buf[0, off:off + f.numel()].view(f.shape), total))
+        off += f.numel()
+    a2_hi = planes_nhwc(nn, a2d.detach().float()).hi
+    a1_hi = planes_nhwc(nn, a1).hi
+    da2 = nn.Planes(batch * 81, 64, device="cuda")
+    da1 = nn.Planes(batch * 400, 32, device="cuda")
+    da2.full.fill_(9.0)
+    da1.full.fill_(9.0)
+    nn.x3_cnn_dgrad_stack(planes_nhwc(nn, da3), a2_hi, a1_hi, views[1], views[0], da2, da1, batch)
+    assert rel(from_nhwc(da2.value(), batch, 9, 9, 64), ref_da2) < TOL
+    assert rel(from_nhwc(da1.value(), batch, 20, 20, 32), ref_da1) < TOL
+
+
 def test_x3_conv_wgrad_pair_and_u8(nn):
     torch.manual_seed(7)
     batch, ks = 12, 768
