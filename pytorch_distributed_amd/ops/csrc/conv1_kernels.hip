@@ -395,6 +395,7 @@ struct FwdStackArgs {
 #define FWD_PLANE 7104  // bf16 elements per channel plane of the forward kernel's frame patch: 84 * 84 + 48, == 32 (mod 64) dwords
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // volatile LDS pointer: keeps two adjacent 8-byte reads as two ds_read_b64 (2 LDS cycles each, 64-bank rules);
 // merged into one ds_read2_b64 they cost 8 cycles under 32-bank rules
 typedef const volatile __attribute__((address_space(3))) u32x2* lds_v2;
@@ -727,34 +728,58 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
     const int img = blockIdx.x;
     bf16_t* patch = lds;
 
+    STACK_STAMP(a.prof, 0, 0)
+    const long wp = a.w_plane;
+    bf16x8 wf1h[KS1][2], wf1l[KS1][2], wf2h[KS2], wf2l[KS2], wf3h[KS3], wf3l[KS3];
+    // conv1's weights go out first, as coalesced 16-byte chunks of the [32][256] tensor, and reach their fragment
+    // registers through LDS (free until the frames arrive).  Loaded straight into fragments -- a lane's rows are 512 B
+    // apart -- every load instruction touches 64 cache lines: 211 cycles per instruction, and with the other weight
+    // loads more than the 63 a wave can keep outstanding (7.9 us from kernel start to the last load issued).
+    u32x4 r1h[4], r1l[4];
+    {
+        const u32x4* sh = reinterpret_cast<const u32x4*>(a.w1[grp]);
+        const u32x4* sl = reinterpret_cast<const u32x4*>(a.w1[grp] + wp);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { r1h[i] = sh[tid + i * 256]; r1l[i] = sl[tid + i * 256]; }
+    }
     PatchRegs pr;
     {
         const long f0 = a.idx[grp] ? (long)a.idx[grp][img] : (long)img;
         patch_issue_at<7>(pr, a.frames[grp] + f0 * frame_bytes, frame_bytes, tid);
     }
-    const long wp = a.w_plane;
-    bf16x8 wf1h[KS1][2], wf1l[KS1][2], wf2h[KS2], wf2l[KS2], wf3h[KS3], wf3l[KS3];
-#pragma unroll
-    for (int ks = 0; ks < KS1; ++ks)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const bf16_t* src = a.w1[grp] + (long)(nb * 16 + l15) * 256 + g4 * 64 + ks * 8;
-            wf1h[ks][nb] = *reinterpret_cast<const bf16x8*>(src);
-            wf1l[ks][nb] = *reinterpret_cast<const bf16x8*>(src + wp);
-        }
+    STACK_STAMP(a.prof, 0, 10)
 #pragma unroll
     for (int ks = 0; ks < KS2; ++ks) {
         const bf16_t* src = a.w2[grp] + (long)(wave * 16 + l15) * 512 + ks * 32 + g4 * 8;
         wf2h[ks] = *reinterpret_cast<const bf16x8*>(src);
         wf2l[ks] = *reinterpret_cast<const bf16x8*>(src + wp);
     }
+    STACK_STAMP(a.prof, 0, 12)
     const bf16_t* w3src = a.w3[grp] + (long)(wave * 16 + l15) * 576 + g4 * 8;
     const f32x4 b10 = *reinterpret_cast<const f32x4*>(a.b1[grp] + 4 * g4);
     const f32x4 b11 = *reinterpret_cast<const f32x4*>(a.b1[grp] + 16 + 4 * g4);
     const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2[grp] + wave * 16 + 4 * g4);
     const f32x4 b3v = *reinterpret_cast<const f32x4*>(a.b3[grp] + wave * 16 + 4 * g4);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
+    {   // w1 -> [32][256 + 8] rows in the (still unused) a1 region -> fragments: 16 lanes x 16 B cover the 64 banks once
+        constexpr int W1S = C * PLANE, W1P = 264;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = tid + i * 256, off = W1S + (t >> 5) * W1P + (t & 31) * 8;
+            *reinterpret_cast<u32x4*>(lds + off) = r1h[i];
+            *reinterpret_cast<u32x4*>(lds + off + 32 * W1P) = r1l[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const bf16_t* q = lds + W1S + (nb * 16 + l15) * W1P + g4 * 64 + ks * 8;
+                wf1h[ks][nb] = *reinterpret_cast<const bf16x8*>(q);
+                wf1l[ks][nb] = *reinterpret_cast<const bf16x8*>(q + 32 * W1P);
+            }
+    }
+    STACK_STAMP(a.prof, 0, 13)
     int ld1[7], st1[7], co1[7], ld2[NRB2], st2[NRB2], co2[3], ld3[NRB3], st3[NRB3];
 #pragma unroll
     for (int it = 0; it < 7; ++it) {
@@ -794,12 +819,14 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
         asm volatile("" : "+v"(ld3[rb]), "+v"(st3[rb]));
     }
 
+    STACK_STAMP(a.prof, 0, 1)
     patch_commit<7, H * W / 16, PLANE - H * W>(pr, frame_bytes, patch, tid);
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
         pin_agpr(wf1h[ks][0]); pin_agpr(wf1h[ks][1]); pin_agpr(wf1l[ks][0]); pin_agpr(wf1l[ks][1]);
     }
+    STACK_STAMP(a.prof, 0, 2)
     // ---- conv1 (frames exact: two products per fragment pair) -> a1s hi / lo
     {
         auto load1 = [&](bf16x8 (&xf)[KS1], int it) {
@@ -854,22 +881,11 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
             store1(cb0, cb1, 5);
         }
     }
+    STACK_STAMP(a.prof, 0, 3)
     __syncthreads();                    // a1 complete; the patch is dead from here on
 #pragma unroll
-    for (int ks = 0; ks < KS3; ++ks) wf3h[ks] = *reinterpret_cast<const bf16x8*>(w3src + ks * 32);
-    if (a.a1[grp]) {                    // coalesced copy-out of both planes for the backward pass
-        uint4* dst = reinterpret_cast<uint4*>(a.a1[grp] + (long)img * P1 * 32);
-        uint4* dstl = reinterpret_cast<uint4*>(a.a1[grp] + a.a1_plane + (long)img * P1 * 32);
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            if (i < 6 || tid < P1 * 4 - 1536) {
-                dst[tid + i * 256] = *reinterpret_cast<const uint4*>(lds + co1[i]);
-                dstl[tid + i * 256] = *reinterpret_cast<const uint4*>(lds + co1[i] + X_A1LO);
-            }
-        }
-    }
-#pragma unroll
     for (int ks = 0; ks < KS2; ++ks) { pin_agpr(wf2h[ks]); pin_agpr(wf2l[ks]); }
+    STACK_STAMP(a.prof, 0, 5)
     // ---- conv2: wave w -> output channels [16 w, 16 w + 16); unit = half the reduction of a row block
     {
         auto load2 = [&](bf16x8 (&xh)[8], bf16x8 (&xl)[8], int rb, int half) {
@@ -913,25 +929,33 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
             if (half == 0 && rb > 0) { if (rb & 1) store2(ca, rb - 1); else store2(cb, rb - 1); }
             STACK_SCHED(24, 2, 3, 3)
             __builtin_amdgcn_sched_barrier(0);
+            // in the shadow of the MFMAs: conv3's weights (conv1's registers are free now) and the coalesced
+            // copy-out of a1 (both planes; a1s is read-only in this phase)
+            if (u == 0) {
+#pragma unroll
+                for (int ks = 0; ks < KS3; ++ks) wf3h[ks] = *reinterpret_cast<const bf16x8*>(w3src + ks * 32);
+            }
+            if (u == 8) {
+#pragma unroll
+                for (int ks = 0; ks < KS3; ++ks) wf3l[ks] = *reinterpret_cast<const bf16x8*>(w3src + wp + ks * 32);
+            }
+            if (u >= 1 && u <= 7 && a.a1[grp]) {
+                const int i = u - 1;
+                if (i < 6 || tid < P1 * 4 - 1536) {
+                    uint4* dst = reinterpret_cast<uint4*>(a.a1[grp] + (long)img * P1 * 32);
+                    uint4* dstl = reinterpret_cast<uint4*>(a.a1[grp] + a.a1_plane + (long)img * P1 * 32);
+                    dst[tid + i * 256] = *reinterpret_cast<const uint4*>(lds + co1[i]);
+                    dstl[tid + i * 256] = *reinterpret_cast<const uint4*>(lds + co1[i] + X_A1LO);
+                }
+            }
         }
         if ((NRB2 - 1) & 1) store2(cb, NRB2 - 1); else store2(ca, NRB2 - 1);
     }
+    STACK_STAMP(a.prof, 0, 6)
     __syncthreads();                    // a2 complete
 #pragma unroll
-    for (int ks = 0; ks < KS3; ++ks) wf3l[ks] = *reinterpret_cast<const bf16x8*>(w3src + wp + ks * 32);
-    if (a.a2[grp]) {
-        uint4* dst = reinterpret_cast<uint4*>(a.a2[grp] + (long)img * P2 * 64);
-        uint4* dstl = reinterpret_cast<uint4*>(a.a2[grp] + a.a2_plane + (long)img * P2 * 64);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            if (i < 2 || tid < P2 * 8 - 512) {
-                dst[tid + i * 256] = *reinterpret_cast<const uint4*>(lds + co2[i]);
-                dstl[tid + i * 256] = *reinterpret_cast<const uint4*>(lds + co2[i] + X_A2LO);
-            }
-        }
-    }
-#pragma unroll
     for (int ks = 0; ks < KS3; ++ks) { pin_agpr(wf3h[ks]); pin_agpr(wf3l[ks]); }
+    STACK_STAMP(a.prof, 0, 8)
     // ---- conv3 -> global a3 hi / lo; unit = 9 of the 18 k-steps of a row block
     {
         bf16_t* out3 = a.a3[grp] + (long)img * P3 * 64;
@@ -977,9 +1001,18 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
             if (half == 0 && rb > 0) { if (rb & 1) store3(ca, rb - 1); else store3(cb, rb - 1); }
             STACK_SCHED(27, 2, 3, 3)
             __builtin_amdgcn_sched_barrier(0);
+            if (u < 3 && a.a2[grp]) {       // copy-out of a2 (both planes) under the MFMAs
+                if (u < 2 || tid < P2 * 8 - 512) {
+                    uint4* dst = reinterpret_cast<uint4*>(a.a2[grp] + (long)img * P2 * 64);
+                    uint4* dstl = reinterpret_cast<uint4*>(a.a2[grp] + a.a2_plane + (long)img * P2 * 64);
+                    dst[tid + u * 256] = *reinterpret_cast<const uint4*>(lds + co2[u]);
+                    dstl[tid + u * 256] = *reinterpret_cast<const uint4*>(lds + co2[u] + X_A2LO);
+                }
+            }
         }
         if ((NRB3 - 1) & 1) store3(cb, NRB3 - 1); else store3(ca, NRB3 - 1);
     }
+    STACK_STAMP(a.prof, 0, 9)
 }
 
 // ---- data-gradient chain per image: da3 -> (conv3^T, relu'(a2)) -> da2 -> (conv2^T, relu'(a1)) -> da1 -----
@@ -1020,7 +1053,6 @@ __device__ __forceinline__ uint2 gate_pack4(uint2 act, f32x4 v) {
     return make_uint2(relu_gate2(act.x, pack2bf(v[0], v[1])), relu_gate2(act.y, pack2bf(v[2], v[3])));
 }
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct DgradRegs { u32x4 a1[7], a2[3], d3[2]; };    // one image's inputs in flight: 1600 + 648 + 392 16-byte chunks
 
 __device__ __forceinline__ void dgrad_issue(DgradRegs& r, const DgradStackArgs& a, int img, int tid) {
@@ -1378,6 +1410,7 @@ struct DgradStackX3Args {
     const bf16_t* da3; const bf16_t* a2; const bf16_t* a1; const bf16_t* w3; const bf16_t* w2;
     bf16_t* da2; bf16_t* da1; int batch;
     long da3_plane, w_plane, da2_plane, da1_plane;
+    long long* prof;    // optional phase stamps (pda_cnn_stack_prof)
 };
 
 // (hi, lo) planes of 4 gradient values, gated by relu'(act): 8 bytes each
@@ -1396,6 +1429,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     const int g4 = lane >> 4, l15 = lane & 15;
     const int img = blockIdx.x;
 
+    STACK_STAMP(a.prof, 0, 0)
     // ---- both planes of both weight tensors and this image's inputs (a1 / a2: hi planes only): in flight together
     u32x4 i1[7], i2[3], i3h[2], i3l[2];
     bf16x8 wf3h[18], wf3l[18];      // conv3^T: this wave's 16 input channels; k-step = (tap, o half)
@@ -1421,30 +1455,21 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         const int l3a = o3 * 64 + (((2 * rg3) ^ swz_t<64>(o3)) << 2);
         const int l3b = (o3 + 32) * 64 + (((2 * rg3) ^ swz_t<64>(o3 + 32)) << 2);
         const int l2 = o2 * 32 + (((2 * rg2) ^ swz_t<32>(o2)) << 2);
-        auto stage3 = [&](const u32x4 (&r)[18], bf16x8 (&wf)[18]) {
+        // both planes of a tensor are staged side by side (2 x 36 864 and 2 x 32 768 elements of the 73 888)
+        constexpr int W3L = 9 * 4096, W2L = 16 * 2048;
 #pragma unroll
-            for (int i = 0; i < 18; ++i)
-                *reinterpret_cast<u32x4*>(lds + (i >> 1) * 4096 + ((i & 1) ? l3b : l3a)) = r[i];
-            __syncthreads();
+        for (int i = 0; i < 18; ++i) {
+            *reinterpret_cast<u32x4*>(lds + (i >> 1) * 4096 + ((i & 1) ? l3b : l3a)) = r3h[i];
+            *reinterpret_cast<u32x4*>(lds + W3L + (i >> 1) * 4096 + ((i & 1) ? l3b : l3a)) = r3l[i];
+        }
+        __syncthreads();
 #pragma unroll
-            for (int ks = 0; ks < 18; ++ks) wf[ks] = read_frag<true, 64, 32>(lds + (ks >> 1) * 4096, wave * 16, ks & 1, lane);
-            __syncthreads();
-        };
-        auto stage2 = [&](const u32x4 (&r)[16], bf16x8 (&wf)[8][2]) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) *reinterpret_cast<u32x4*>(lds + i * 2048 + l2) = r[i];
-            __syncthreads();
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {       // t = (a * 2 + b) * 2 + half
-                int ta = t >> 2, tb = (t >> 1) & 1, half = t & 1;
-                int tap = (py + 2 * ta) * 4 + (px + 2 * tb);
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) wf[t][nb] = read_frag<true, 32, 32>(lds + tap * 2048, nb * 16, half, lane);
-            }
-            __syncthreads();
-        };
-        stage3(r3h, wf3h);
-        {   // this image's inputs go out behind the first weight plane (they are consumed after the staging)
+        for (int ks = 0; ks < 18; ++ks) {
+            wf3h[ks] = read_frag<true, 64, 32>(lds + (ks >> 1) * 4096, wave * 16, ks & 1, lane);
+            wf3l[ks] = read_frag<true, 64, 32>(lds + W3L + (ks >> 1) * 4096, wave * 16, ks & 1, lane);
+        }
+        STACK_STAMP(a.prof, 0, 1)
+        {   // this image's inputs go out behind the weights (they are consumed after the staging)
             const u32x4* s1 = reinterpret_cast<const u32x4*>(a.a1 + (long)img * 400 * 32);
             const u32x4* s2 = reinterpret_cast<const u32x4*>(a.a2 + (long)img * 81 * 64);
             const u32x4* s3 = reinterpret_cast<const u32x4*>(a.da3 + (long)img * 49 * 64);
@@ -1456,12 +1481,28 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
 #pragma unroll
             for (int i = 0; i < 2; ++i) { int t = tid + i * 256; i3h[i] = s3[t < 392 ? t : 0]; i3l[i] = s3l[t < 392 ? t : 0]; }
         }
-        stage3(r3l, wf3l);
-        stage2(r2h, wf2h);
-        stage2(r2l, wf2l);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            *reinterpret_cast<u32x4*>(lds + i * 2048 + l2) = r2h[i];
+            *reinterpret_cast<u32x4*>(lds + W2L + i * 2048 + l2) = r2l[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {       // t = (a * 2 + b) * 2 + half
+            int ta = t >> 2, tb = (t >> 1) & 1, half = t & 1;
+            int tap = (py + 2 * ta) * 4 + (px + 2 * tb);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                wf2h[t][nb] = read_frag<true, 32, 32>(lds + tap * 2048, nb * 16, half, lane);
+                wf2l[t][nb] = read_frag<true, 32, 32>(lds + W2L + tap * 2048, nb * 16, half, lane);
+            }
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int ks = 0; ks < 18; ++ks) { pin_agpr(wf3h[ks]); pin_agpr(wf3l[ks]); }
+    STACK_STAMP(a.prof, 0, 2)
     // the four grids start out all zero; the image only writes their interiors
     for (int t = tid; t < (DX_LDS_ELEMS - DX_A2H) / 8; t += 256)
         *reinterpret_cast<uint4*>(lds + DX_A2H + t * 8) = make_uint4(0, 0, 0, 0);
@@ -1525,6 +1566,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     }
     __syncthreads();
 
+    STACK_STAMP(a.prof, 0, 3)
     // ---- conv3^T: da2[(iy,ix)][c] = sum_{tap,o} w3[o][tap][c] da3[(iy-ky, ix-kx)][o], times relu'(a2); a unit is a
     // third (6 k-steps) of a row block's reduction
     {
@@ -1574,6 +1616,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         }
         if ((NRB3 - 1) & 1) store(cb, NRB3 - 1); else store(ca, NRB3 - 1);
     }
+    STACK_STAMP(a.prof, 0, 4)
     __syncthreads();                    // the a2 grids now hold da2 (hi, lo)
     {
         uint4* dst = reinterpret_cast<uint4*>(a.da2 + (long)img * P2 * 64);
@@ -1588,6 +1631,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) { pin_agpr(wf2h[t][0]); pin_agpr(wf2h[t][1]); pin_agpr(wf2l[t][0]); pin_agpr(wf2l[t][1]); }
+    STACK_STAMP(a.prof, 0, 5)
     // ---- conv2^T for this wave's parity class: input pixel (2 iy2 + py, 2 ix2 + px), taps (py + 2a, px + 2b)
     {
         auto load = [&](bf16x8 (&xh)[8], bf16x8 (&xl)[8], int rb) {
@@ -1639,6 +1683,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         }
         if ((NRB2 - 1) & 1) store(cb0, cb1, NRB2 - 1); else store(ca0, ca1, NRB2 - 1);
     }
+    STACK_STAMP(a.prof, 0, 6)
     __syncthreads();                    // the a1 rows now hold da1 (hi), the rows behind them its lo plane
     {
         uint4* dst = reinterpret_cast<uint4*>(a.da1 + (long)img * P1 * 32);
@@ -1651,6 +1696,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
             }
         }
     }
+    STACK_STAMP(a.prof, 0, 7)
 }
 
 // ---- conv2 + conv3 weight gradients per image (large batches) -------------------------------------------
@@ -1990,7 +2036,7 @@ PDA_EXPORT void pda_cnn_fwd_stack_x3(const void* const* frames, const void* cons
         a.w3[i] = (const bf16_t*)w3[i]; a.b3[i] = (const float*)b3[i];
         a.a1[i] = (bf16_t*)a1[i]; a.a2[i] = (bf16_t*)a2[i]; a.a3[i] = (bf16_t*)a3[i];
     }
-    a.batch = batch; a.scale = scale; a.prof = nullptr;
+    a.batch = batch; a.scale = scale; a.prof = g_stack_prof;
     a.w_plane = w_plane; a.a1_plane = a1_plane; a.a2_plane = a2_plane; a.a3_plane = a3_plane;
     size_t lds = ((size_t)4 * FWD_PLANE + 2 * (size_t)X_A1LO) * 2;
     static bool attr_set = false;
@@ -2039,7 +2085,8 @@ PDA_EXPORT void pda_cnn_dgrad_stack_x3(const void* da3, long da3_plane, const vo
                                        const void* w3, const void* w2, long w_plane, void* da2, long da2_plane,
                                        void* da1, long da1_plane, int batch, hipStream_t stream) {
     DgradStackX3Args a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3,
-                          (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch, da3_plane, w_plane, da2_plane, da1_plane};
+                          (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch, da3_plane, w_plane, da2_plane, da1_plane,
+                          g_stack_prof};
     static_assert(DX_LDS_ELEMS >= 9 * 4096 && DX_LDS_ELEMS * 2 <= 160 * 1024, "weight staging / LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
