@@ -443,6 +443,7 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
     // conv1's weights first, as coalesced 16-byte chunks of the [32][256] tensor; they reach their fragment registers
     // through LDS below (a lane's fragment rows are 512 B apart in memory: loaded directly, every instruction touches
     // 64 cache lines -- 211 cycles per load instruction in the fp32-precision kernel's prologue)
+    STACK_STAMP(a.prof, 0, 10)
     u32x4 r1[4];
     {
         const u32x4* sw = reinterpret_cast<const u32x4*>(a.w1[grp]);
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
     const f32x4 b3v = *reinterpret_cast<const f32x4*>(a.b3[grp] + wave * 16 + 4 * g4);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     int it_no = 0;
+    STACK_STAMP(a.prof, 0, 11)
     {   // w1 -> [32][256 + 8] rows in the (still unused) a1 region -> fragments: 16 lanes x 16 B cover the 64 banks once
         constexpr int W1S = C * PLANE, W1P = 264;
 #pragma unroll
@@ -486,6 +488,7 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
             for (int nb = 0; nb < 2; ++nb)
                 wf1[ks][nb] = *reinterpret_cast<const bf16x8*>(lds + W1S + (nb * 16 + l15) * W1P + g4 * 64 + ks * 8);
     }
+    STACK_STAMP(a.prof, 0, 12)
     // Per-lane LDS offsets (bf16 elements) of every fragment gather, output store and copy-out chunk, computed
     // here -- in the shadow of the first frame / weight loads -- and made opaque so that the divisions are not
     // re-materialised inside the phases (a workgroup with a single image has no loop to hoist them out of).

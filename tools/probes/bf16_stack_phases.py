@@ -25,6 +25,6 @@ for rep in range(3):
     L.pda_cnn_stack_prof(ctypes.c_void_p(0))
 p = prof.cpu()[:16].tolist()
 names = ["loop top", "committed", "conv1 done", "barrier", "a1 out", "pinned", "conv2 done", "barrier", "a2 out", "conv3 done"]
-print("bf16 forward stack, batch %d (stamp 0 is taken after the prologue: loads issued, offsets computed)" % B)
+print("bf16 forward stack, batch %d; prologue (cycles before the loop top): kernel entry %d, loads issued %d, w1 staged %d" % (B, p[10] - p[0], p[11] - p[0], p[12] - p[0]))
 for i, n in enumerate(names):
     print("   %-12s %8d %8d" % (n, p[i] - p[0], p[i] - p[max(i - 1, 0)]))
