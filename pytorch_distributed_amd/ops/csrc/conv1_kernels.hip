@@ -1432,6 +1432,9 @@ struct DgradStackX3Args {
     bf16_t* da2; bf16_t* da1; int batch;
     long da3_plane, w_plane, da2_plane, da1_plane;
     long long* prof;    // optional phase stamps (pda_cnn_stack_prof)
+    // optional tail (W1): conv1's weight gradient of the same image, from da1 (hi, lo) while it is still in LDS;
+    // slab slice blockIdx.x
+    const uint8_t* frames; const int* idx; float* gw1; float* gb1; long ws1, bs1; float scale1;
 };
 
 // (hi, lo) planes of 4 gradient values, gated by relu'(act): 8 bytes each
@@ -1443,12 +1446,20 @@ __device__ __forceinline__ void gate_split4(uint2 act, f32x4 v, uint2& hi, uint2
     lo = make_uint2(relu_gate2(act.x, pack2bf(r0, r1)), relu_gate2(act.y, pack2bf(r2, r3)));
 }
 
+// W1: the frame patch of the image (bf16, exact) is committed over the dead a2 / da3 grids once conv2^T is done, and
+// the workgroup adds dW1 = da1^T im2col(frames) of its image with both planes of da1 read straight from LDS (as in
+// cnn_dgrad_stack_kernel<., true>): one launch and one round trip of da1 through memory less per step.
+template <bool W1>
 __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Args a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     constexpr int P1 = 400, P2 = 81, P3 = 49, NRB3 = 6, NRB2 = 7;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, l15 = lane & 15;
     const int img = blockIdx.x;
+    constexpr int FH = 84, FW = 84;
+    constexpr long frame_bytes = 4L * FH * FW;
+    long f0 = 0;
+    if constexpr (W1) f0 = frame_index(a.idx, img, a.batch);      // a per-lane load with a counted wait at its use
 
     STACK_STAMP(a.prof, 0, 0)
     // ---- both planes of both weight tensors and this image's inputs (a1 / a2: hi planes only): in flight together
@@ -1652,6 +1663,8 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) { pin_agpr(wf2h[t][0]); pin_agpr(wf2h[t][1]); pin_agpr(wf2l[t][0]); pin_agpr(wf2l[t][1]); }
+    PatchRegs pr;
+    if constexpr (W1) patch_issue_at<7>(pr, a.frames + f0 * frame_bytes, frame_bytes, tid);     // flies under conv2^T
     STACK_STAMP(a.prof, 0, 5)
     // ---- conv2^T for this wave's parity class: input pixel (2 iy2 + py, 2 ix2 + px), taps (py + 2a, px + 2b)
     {
@@ -1718,6 +1731,88 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         }
     }
     STACK_STAMP(a.prof, 0, 7)
+    if constexpr (W1) {
+        // ---- conv1 weight gradient: dW1[o][(c, ky, kx)] = sum_px da1[px][o] patch[c][4 oy + ky][4 ox + kx];
+        // wave w = kernel channel w, 13 chunks of 32 pixels; pixels >= 400 read a zeroed strip behind the patch
+        constexpr int P1 = 400;
+        bf16_t* patch = lds + DX_A2H;
+        constexpr int ZOFF = DX_A2H + 4 * FH * FW;
+        static_assert(ZOFF + 64 <= DX_LDS_ELEMS, "zero strip");
+        patch_commit<7>(pr, frame_bytes, patch, tid);       // every wave is past the barrier that closed conv2^T
+        if (tid < 8) *reinterpret_cast<uint4*>(lds + ZOFF + tid * 8) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+        f32x4 acc1[2][4], accb1[2];
+        int boff[4];
+        bf16x8 ones;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            accb1[i] = zero4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1[i][j] = zero4;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) boff[j] = wave * FH * FW + (2 * j + (tp >> 1)) * FW + 4 * (tp & 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+        auto load = [&](bf16x8 (&fa)[4], bf16x8 (&fb)[4], int ch) {
+            int p0 = ch * 32 + 8 * tg + tq, p1 = p0 + 4;
+            const bool in0 = p0 < P1, in1 = p1 < P1;
+            int a0 = (in0 ? p0 * D1_CP : ZOFF) + 4 * tp, a1o = (in1 ? p1 * D1_CP : ZOFF) + 4 * tp;
+            int l0 = in0 ? DX_A1L : 0, l1 = in1 ? DX_A1L : 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = tr_frag(lds + a0 + i * 16, lds + a1o + i * 16);
+                fa[2 + i] = tr_frag(lds + a0 + l0 + i * 16, lds + a1o + l1 + i * 16);
+            }
+            int q0 = in0 ? p0 : 0, q1 = in1 ? p1 : 0;
+            const bf16_t* b0 = patch + (4 * (q0 / 20)) * FW + 4 * (q0 % 20);
+            const bf16_t* b1 = patch + (4 * (q1 / 20)) * FW + 4 * (q1 % 20);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = tr_frag(b0 + boff[j], b1 + boff[j]);
+        };
+        auto mma = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc1[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2 + i], fb[j], acc1[i][j], 0, 0, 0);
+                }
+                if (wave == 0) {
+                    accb1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb1[i], 0, 0, 0);
+                    accb1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2 + i], ones, accb1[i], 0, 0, 0);
+                }
+            }
+        };
+        bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+        load(fa0, fb0, 0);
+#pragma unroll 1
+        for (int ch = 0; ch < 12; ch += 2) {        // chunks ch, ch + 1; fragments one chunk ahead
+            load(fa1, fb1, ch + 1);
+            mma(fa0, fb0);
+            load(fa0, fb0, ch + 2);
+            mma(fa1, fb1);
+        }
+        mma(fa0, fb0);                              // chunk 12
+        // [32][256] tile -> slab slice blockIdx.x (kernel layout == PyTorch's (c, ky, kx))
+        float* dw = a.gw1 + (long)blockIdx.x * a.ws1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int o = i * 16 + g4 * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int k = wave * 64 + j * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dw[(long)(o + r) * 256 + k] = acc1[i][j][r] * a.scale1;
+            }
+            if (wave == 0 && l15 == 0 && a.gb1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a.gb1[(long)blockIdx.x * a.bs1 + o + r] = accb1[i][r];
+            }
+        }
+        STACK_STAMP(a.prof, 0, 8)
+    }
 }
 
 // ---- conv2 + conv3 weight gradients per image (large batches) -------------------------------------------
@@ -2102,20 +2197,28 @@ PDA_EXPORT void pda_cnn_dgrad_stack(const void* da3, const void* a2, const void*
 }
 
 // the chain at fp32 precision: da3 / da2 / da1 and the weights as (hi, lo) planes, a2 / a1 hi planes (relu masks)
+// frames != null: the launch also writes conv1's weight gradient, one slab slice (ws1 / bs1 floats apart) per image
 PDA_EXPORT void pda_cnn_dgrad_stack_x3(const void* da3, long da3_plane, const void* a2, const void* a1,
                                        const void* w3, const void* w2, long w_plane, void* da2, long da2_plane,
-                                       void* da1, long da1_plane, int batch, hipStream_t stream) {
+                                       void* da1, long da1_plane, int batch, const void* frames, const void* idx,
+                                       void* gw1, void* gb1, long ws1, long bs1, float scale1, hipStream_t stream) {
     DgradStackX3Args a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3,
                           (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch, da3_plane, w_plane, da2_plane, da1_plane,
-                          g_stack_prof};
+                          g_stack_prof, (const uint8_t*)frames, (const int*)idx, (float*)gw1, (float*)gb1, ws1, bs1,
+                          scale1};
     static_assert(DX_LDS_ELEMS >= 9 * 4096 && DX_LDS_ELEMS * 2 <= 160 * 1024, "weight staging / LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_x3_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_x3_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_x3_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(cnn_dgrad_stack_x3_kernel, dim3(batch), dim3(256), (size_t)DX_LDS_ELEMS * 2, stream, a);
+    if (frames)
+        hipLaunchKernelGGL(cnn_dgrad_stack_x3_kernel<true>, dim3(batch), dim3(256), (size_t)DX_LDS_ELEMS * 2, stream, a);
+    else
+        hipLaunchKernelGGL(cnn_dgrad_stack_x3_kernel<false>, dim3(batch), dim3(256), (size_t)DX_LDS_ELEMS * 2, stream, a);
 }
 
 // same, plus conv1's weight gradient from uint8 frames (slab slice per workgroup: pda_cnn_dgrad_stack_slices(batch))

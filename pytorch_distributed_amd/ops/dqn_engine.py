@@ -369,6 +369,9 @@ class DqnCnnEngine(object):
         # conv1's weight gradient as a tail of the dgrad stack launch (da1 still in LDS)
         self.fuse_w1 = (bool(self.acts.stack_dgrad) and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32)
                         and os.environ.get("PDA_FUSE_W1", "1") != "0" and not x3)
+        # the same for the fp32-precision dgrad stack (one workgroup = one slab slice per image: small batches)
+        self.x3_fuse_w1 = (x3 and nn.x3_cnn_dgrad_stack_supported(g.H, g.W, g.C) and self.B <= 256
+                           and os.environ.get("PDA_FUSE_W1", "1") != "0")
         self._plan_wgrads()
         self._fc_pair = None
         self.idx = torch.zeros(self.B, dtype=torch.int32, device=dev)
@@ -424,6 +427,8 @@ class DqnCnnEngine(object):
                 ns = nn.conv1_wgrad_slices(B)       # whole-image kernel: one slice per workgroup
                 if self.fuse_w1 and not self.x3:
                     ns = nn.cnn_dgrad_stack_slices(B)   # computed by the dgrad stack launch itself
+                if self.x3_fuse_w1:
+                    ns = B                              # fp32-precision dgrad stack: one slice per image
             plans.append((li, O, K, ks, ns))
         self.wg_plan = plans
         total = sum(ns * (O * K + O) for _, O, K, _, ns in plans)
@@ -566,11 +571,25 @@ class DqnCnnEngine(object):
                                    act=nn.ACT_RELU)
             if nn.x3_cnn_dgrad_stack_supported(g.H, g.W, g.C):
                 # both conv data gradients in one launch (per image, every plane LDS-resident)
-                nn.x3_cnn_dgrad_stack(a.da3, a.a2[0].hi, a.a1[0].hi, on.w[2], on.w[1], a.da2, a.da1, B)
+                nn.x3_cnn_dgrad_stack(a.da3, a.a2[0].hi, a.a1[0].hi, on.w[2], on.w[1], a.da2, a.da1, B,
+                                      w1=(s0, idx, w1s, b1s, 1.0 / self.norm_val) if self.x3_fuse_w1 else None)
             else:
                 nn.x3_conv_dgrad(a.da3, on.w[2], a.a2[0].hi, a.da2, B, g.H2, g.W2, 64, 3, 3, 1, 64, act=nn.ACT_RELU)
                 nn.x3_conv_dgrad(a.da2, on.w[1], a.a1[0].hi, a.da1, B, g.H1, g.W1, 32, 4, 4, 2, 64, act=nn.ACT_RELU)
             geoms = [(g.H1, g.W1, 32, 4, 4, 2), (g.H2, g.W2, 64, 3, 3, 1)]
+
+            def conv1_wgrad():
+                if self.x3_fuse_w1:
+                    return          # done by the dgrad stack launch
+                if nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32):
+                    nn.x3_conv1_wgrad_u8_whole(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 1.0 / self.norm_val, st1,
+                                               bst1)
+                else:
+                    nn.x3_conv_wgrad_u8(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / self.norm_val,
+                                        ksplit=ks1, slice_stride=st1, bslice_stride=bst1)
+            # conv1's weight gradient (one workgroup per CU, LDS-bound occupancy) beside the conv2 / conv3 pair
+            # (PDA_OVERLAP_WGRAD=1: a forked branch of the step's graph)
+            on_side(self.ev_da2, conv1_wgrad)
             if self.pair_wgrad:
                 assert ks2 == ks3
                 nn.x3_conv_wgrad([a.da2, a.da3], [a.a1[0], a.a2[0]], [w2s, w3s], [b2s, b3s], B, geoms, 64, ks2,
@@ -578,11 +597,9 @@ class DqnCnnEngine(object):
             else:
                 nn.x3_conv_wgrad([a.da3], [a.a2[0]], [w3s], [b3s], B, geoms[1:], 64, ks3, [st3], [bst3])
                 nn.x3_conv_wgrad([a.da2], [a.a1[0]], [w2s], [b2s], B, geoms[:1], 64, ks2, [st2], [bst2])
-            if nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32):
-                nn.x3_conv1_wgrad_u8_whole(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 1.0 / self.norm_val, st1, bst1)
-            else:
-                nn.x3_conv_wgrad_u8(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / self.norm_val,
-                                    ksplit=ks1, slice_stride=st1, bslice_stride=bst1)
+            if fork:
+                self.ev_side.record(side)
+                cur.wait_event(self.ev_side)
             if reduce:
                 self.reduce.run()
             return False

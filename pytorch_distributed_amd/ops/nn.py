@@ -460,7 +460,8 @@ def _X():
         L.pda_cnn_fwd_stack_x3.argtypes = ([_vp] * 8 + [c_long, _vp, c_long, _vp, c_long, _vp, c_long] + [c_int] * 5 +
                                            [c_float, _vp])
         L.pda_cnn_fwd_stack_x3.restype = None
-        L.pda_cnn_dgrad_stack_x3.argtypes = [_vp, c_long, _vp, _vp, _vp, _vp, c_long, _vp, c_long, _vp, c_long, c_int, _vp]
+        L.pda_cnn_dgrad_stack_x3.argtypes = ([_vp, c_long, _vp, _vp, _vp, _vp, c_long, _vp, c_long, _vp, c_long, c_int] +
+                                             [_vp] * 4 + [c_long, c_long, c_float, _vp])
         L.pda_cnn_dgrad_stack_x3.restype = None
         for name in ("pda_x3_conv_fwd_u8", "pda_x3_conv_fwd", "pda_x3_linear_fwd", "pda_x3_linear_dgrad",
                      "pda_x3_conv_dgrad", "pda_x3_linear_wgrad2", "pda_x3_fc_backward_duo", "pda_x3_conv_wgrad",
@@ -515,12 +516,16 @@ def x3_cnn_dgrad_stack_supported(H, W, C):
     return os.environ.get("PDA_X3_FUSED_BWD", "1") != "0" and bool(_L().pda_cnn_dgrad_stack_supported(H, W, C))
 
 
-def x3_cnn_dgrad_stack(da3, a2_hi, a1_hi, w3, w2, da2, da1, batch):
+def x3_cnn_dgrad_stack(da3, a2_hi, a1_hi, w3, w2, da2, da1, batch, w1=None):
     """da3 -> da2 -> da1 on split planes in one launch (cnn_dgrad_stack_x3_kernel): da* and the weights as Planes
-    (both weights in one shadow buffer: one plane offset), a2 / a1 the hi planes of the forward activations."""
+    (both weights in one shadow buffer: one plane offset), a2 / a1 the hi planes of the forward activations.
+    w1 = (frames uint8, idx int32 or None, gw slab [batch][32*256], gb slab [batch][32], scale): the same launch also
+    leaves conv1's weight / bias gradient, one slab slice per image."""
     assert _plane(w3) == _plane(w2)
+    frames, idx, gw, gb, scale = w1 if w1 is not None else (None, None, None, None, 1.0)
     _X().pda_cnn_dgrad_stack_x3(_ptr(da3), _plane(da3), _ptr(a2_hi), _ptr(a1_hi), _ptr(w3), _ptr(w2), _plane(w3),
-                                _ptr(da2), _plane(da2), _ptr(da1), _plane(da1), batch, _stream())
+                                _ptr(da2), _plane(da2), _ptr(da1), _plane(da1), batch, _ptr(frames), _ptr(idx),
+                                _ptr(gw), _ptr(gb), 32 * 256, 32, float(scale), _stream())
 
 
 def x3_conv_fwd(x, w, bias, out, batch, H, W, C, KH, KW, S, O, act=ACT_RELU):

@@ -195,6 +195,21 @@ def test_x3_cnn_dgrad_stack(nn, batch):
     nn.x3_cnn_dgrad_stack(planes_nhwc(nn, da3), a2_hi, a1_hi, views[1], views[0], da2, da1, batch)
     assert rel(from_nhwc(da2.value(), batch, 9, 9, 64), ref_da2) < TOL
     assert rel(from_nhwc(da1.value(), batch, 20, 20, 32), ref_da1) < TOL
+    # the same launch with conv1's weight gradient as its tail: one slab slice per image, frames through an index
+    mem = torch.randint(0, 256, (40, 4, 84, 84), dtype=torch.uint8, device="cuda")
+    idx = torch.randint(0, 40, (batch,), dtype=torch.int32, device="cuda")
+    gw = torch.full((batch, 32 * 256), 7.0, device="cuda")
+    gb = torch.full((batch, 32), 7.0, device="cuda")
+    da2.full.fill_(9.0)
+    da1.full.fill_(9.0)
+    nn.x3_cnn_dgrad_stack(planes_nhwc(nn, da3), a2_hi, a1_hi, views[1], views[0], da2, da1, batch,
+                          w1=(mem, idx, gw, gb, 1.0 / 255.0))
+    assert rel(from_nhwc(da1.value(), batch, 20, 20, 32), ref_da1) < TOL
+    x = mem[idx.long()].double() / 255.0
+    cols = F.unfold(x, kernel_size=8, stride=4)                     # [B, 256 (c, ky, kx), 400]
+    ref_gw = torch.einsum("bop,bkp->ok", ref_da1.reshape(batch, 32, 400), cols)
+    assert rel(gw.sum(0).view(32, 256), ref_gw) < TOL
+    assert rel(gb.sum(0), ref_da1.sum(dim=(0, 2, 3))) < TOL
 
 
 def test_x3_conv_wgrad_pair_and_u8(nn):
