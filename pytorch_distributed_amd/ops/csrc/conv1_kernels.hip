@@ -952,14 +952,11 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             // in the shadow of the MFMAs: conv3's weights (conv1's registers are free now) and the coalesced
             // copy-out of a1 (both planes; a1s is read-only in this phase)
-            if (u == 0) {
 #pragma unroll
-                for (int ks = 0; ks < KS3; ++ks) wf3h[ks] = *reinterpret_cast<const bf16x8*>(w3src + ks * 32);
-            }
-            if (u == 8) {
-#pragma unroll
-                for (int ks = 0; ks < KS3; ++ks) wf3l[ks] = *reinterpret_cast<const bf16x8*>(w3src + wp + ks * 32);
-            }
+            for (int l = 4 * u; l < 4 * u + 4; ++l) {       // four of the 36 fragment loads per unit (the queue stays
+                if (l < KS3) wf3h[l] = *reinterpret_cast<const bf16x8*>(w3src + l * 32);         // shallow; the last
+                else if (l < 2 * KS3) wf3l[l - KS3] = *reinterpret_cast<const bf16x8*>(w3src + wp + (l - KS3) * 32);
+            }                                                                                    // three units: none)
             if (u >= 1 && u <= 7 && a.a1[grp]) {
                 const int i = u - 1;
                 if (i < 6 || tid < P1 * 4 - 1536) {
