@@ -769,12 +769,10 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
         patch_issue_at<7>(pr, a.frames[grp] + f0 * frame_bytes, frame_bytes, tid);
     }
     STACK_STAMP(a.prof, 0, 10)
-#pragma unroll
-    for (int ks = 0; ks < KS2; ++ks) {
-        const bf16_t* src = a.w2[grp] + (long)(wave * 16 + l15) * 512 + ks * 32 + g4 * 8;
-        wf2h[ks] = *reinterpret_cast<const bf16x8*>(src);
-        wf2l[ks] = *reinterpret_cast<const bf16x8*>(src + wp);
-    }
+    // conv2's weights are fetched under conv1's MFMAs, conv3's under conv2's: issued here they would share the L2 -> L1
+    // path with the frames and conv1's weights, which the first MFMA waits for (190 KB per workgroup, 256 workgroups
+    // at once: 11.6 k cycles from kernel start to the patch commit)
+    const bf16_t* w2src = a.w2[grp] + (long)(wave * 16 + l15) * 512 + g4 * 8;
     STACK_STAMP(a.prof, 0, 12)
     const bf16_t* w3src = a.w3[grp] + (long)(wave * 16 + l15) * 576 + g4 * 8;
     const f32x4 b10 = *reinterpret_cast<const f32x4*>(a.b1[grp] + 4 * g4);
@@ -892,6 +890,11 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
             if (it > 0) { if (it & 1) store1(ca0, ca1, it - 1); else store1(cb0, cb1, it - 1); }
             STACK_SCHED(4 * KS1, 1, 2, 3)
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int l = 6 * it; l < 6 * it + 6; ++l) {     // six of conv2's 32 weight-fragment loads per row block
+                if (l < KS2) wf2h[l] = *reinterpret_cast<const bf16x8*>(w2src + l * 32);
+                else if (l < 2 * KS2) wf2l[l - KS2] = *reinterpret_cast<const bf16x8*>(w2src + wp + (l - KS2) * 32);
+            }
         }
         if (wave == 0) {
             mul1(xa, ca0, ca1);
