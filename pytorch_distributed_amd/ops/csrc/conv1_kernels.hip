@@ -460,12 +460,18 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
     // weight fragments (lane: channel n = l15 + 16 nb, 8 consecutive k).  conv1's k-steps are regrouped as
     // (ky = ks, c = g4, kx 0..7) -- any order works as long as both operands agree -- see conv1 below.
     bf16x8 wf1[KS1][2], wf2[KS2], wf3[KS3];
+    // One image per workgroup: conv2's / conv3's weights are fetched under conv1's / conv2's MFMAs (issued here they
+    // share the L2 -> L1 path with the frames and conv1's weights, which the first MFMA waits for: 12.8 k cycles from
+    // kernel entry to the first image's commit, 5.5 k now).  MULTI: the weights serve every image of the workgroup
+    // and are fetched once, here.
+    const bf16_t* w2src = a.w2[grp] + (long)(wave * 16 + l15) * 512 + g4 * 8;
+    const bf16_t* w3src = a.w3[grp] + (long)(wave * 16 + l15) * 576 + g4 * 8;
+    if constexpr (MULTI) {
 #pragma unroll
-    for (int ks = 0; ks < KS2; ++ks)
-        wf2[ks] = *reinterpret_cast<const bf16x8*>(a.w2[grp] + (long)(wave * 16 + l15) * 512 + ks * 32 + g4 * 8);
+        for (int ks = 0; ks < KS2; ++ks) wf2[ks] = *reinterpret_cast<const bf16x8*>(w2src + ks * 32);
 #pragma unroll
-    for (int ks = 0; ks < KS3; ++ks)
-        wf3[ks] = *reinterpret_cast<const bf16x8*>(a.w3[grp] + (long)(wave * 16 + l15) * 576 + ks * 32 + g4 * 8);
+        for (int ks = 0; ks < KS3; ++ks) wf3[ks] = *reinterpret_cast<const bf16x8*>(w3src + ks * 32);
+    }
     // biases of the 4 channels a lane owns in the swapped product
     const f32x4 b10 = *reinterpret_cast<const f32x4*>(a.b1[grp] + 4 * g4);
     const f32x4 b11 = *reinterpret_cast<const f32x4*>(a.b1[grp] + 16 + 4 * g4);
@@ -592,6 +598,11 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
                 if (it > 0) { if (it & 1) store1(ca0, ca1, it - 1); else store1(cb0, cb1, it - 1); }
                 STACK_SCHED(2 * KS1, 1, 1, 2)
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!MULTI) {
+#pragma unroll
+                    for (int l = 3 * it; l < 3 * it + 3 && l < KS2; ++l)
+                        wf2[l] = *reinterpret_cast<const bf16x8*>(w2src + l * 32);
+                }
             }
             if (wave == 0) {
                 mul1(xa, ca0, ca1);                     // it = 6
@@ -653,6 +664,11 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
                 if (rb > 0) { if (rb & 1) store2(ca0, ca1, rb - 1); else store2(cb0, cb1, rb - 1); }
                 STACK_SCHED(KS2, 1, 1, 2)
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!MULTI) {
+#pragma unroll
+                    for (int l = 4 * rb; l < 4 * rb + 4 && l < KS3; ++l)
+                        wf3[l] = *reinterpret_cast<const bf16x8*>(w3src + l * 32);
+                }
             }
             if ((NRB2 - 1) & 1) store2(cb0, cb1, NRB2 - 1); else store2(ca0, ca1, NRB2 - 1);
         }
