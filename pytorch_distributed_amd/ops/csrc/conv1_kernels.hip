@@ -1444,7 +1444,8 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
 #define DX_LDS_ELEMS (DX_D3L + 11 * D3_RP)
 
 struct DgradStackX3Args {
-    const bf16_t* da3; const bf16_t* a2; const bf16_t* a1; const bf16_t* w3; const bf16_t* w2;
+    const bf16_t* da3; const bf16_t* a2; const bf16_t* a1;
+    const bf16_t* w3t; const bf16_t* w2t;       // TRANSPOSED weight shadows [(tap, c)][o] (csrc/optim.h SegEntry::tr_off)
     bf16_t* da2; bf16_t* da1; int batch;
     long da3_plane, w_plane, da2_plane, da1_plane;
     long long* prof;    // optional phase stamps (pda_cnn_stack_prof)
@@ -1478,85 +1479,49 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     if constexpr (W1) f0 = frame_index(a.idx, img, a.batch);      // a per-lane load with a counted wait at its use
 
     STACK_STAMP(a.prof, 0, 0)
-    // ---- both planes of both weight tensors and this image's inputs (a1 / a2: hi planes only): in flight together
+    // ---- conv3's weight fragments (both planes) and this image's inputs (a1 / a2: hi planes only) go out together;
+    // conv2's fragments are fetched under conv3^T.  The fragments -- rows = input channel, k = output channel -- come
+    // straight from the transposed shadows the optimizer keeps: 16 bytes per lane and fragment, no staging.  (Transposed
+    // through LDS at the start of the launch, as the bf16 kernel does, the four tensors cost 8 barriers and 10 k cycles
+    // before the first MFMA.)
     u32x4 i1[7], i2[3], i3h[2], i3l[2];
+    int in1[7], in2[3], in3[2];
+    int ld3[NRB3], st3[NRB3], ld2[NRB2], st2[NRB2];
     bf16x8 wf3h[18], wf3l[18];      // conv3^T: this wave's 16 input channels; k-step = (tap, o half)
     bf16x8 wf2h[8][2], wf2l[8][2];  // conv2^T: this wave's parity class; (tap a,b ; o half) x 2 channel blocks
     const int py = wave >> 1, px = wave & 1;
-    {
-        u32x4 r3h[18], r3l[18], r2h[16], r2l[16];
-        // chunk i of a thread: w3 (tap = i / 2, o = tid / 8 + 32 (i % 2), rg = tid % 8), w2 (tap = i, o = tid / 4,
-        // rg = tid % 4) -- constant offsets from one per-lane base, so the 68 loads share a few address registers
-        const bf16_t* p3 = a.w3 + (long)(tid >> 3) * 576 + (tid & 7) * 8;
-        const bf16_t* p2 = a.w2 + (long)(tid >> 2) * 512 + (tid & 3) * 8;
+    const bf16_t* w3src = a.w3t + (long)(wave * 16 + l15) * 64 + g4 * 8;
+    const bf16_t* w2src = a.w2t + (long)l15 * 64 + g4 * 8;
 #pragma unroll
-        for (int i = 0; i < 18; ++i) {
-            r3h[i] = *reinterpret_cast<const u32x4*>(p3 + (i & 1) * 32 * 576 + (i >> 1) * 64);
-            r3l[i] = *reinterpret_cast<const u32x4*>(p3 + a.w_plane + (i & 1) * 32 * 576 + (i >> 1) * 64);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            r2h[i] = *reinterpret_cast<const u32x4*>(p2 + i * 32);
-            r2l[i] = *reinterpret_cast<const u32x4*>(p2 + a.w_plane + i * 32);
-        }
-        const int o3 = tid >> 3, rg3 = tid & 7, o2 = tid >> 2, rg2 = tid & 3;
-        const int l3a = o3 * 64 + (((2 * rg3) ^ swz_t<64>(o3)) << 2);
-        const int l3b = (o3 + 32) * 64 + (((2 * rg3) ^ swz_t<64>(o3 + 32)) << 2);
-        const int l2 = o2 * 32 + (((2 * rg2) ^ swz_t<32>(o2)) << 2);
-        // both planes of a tensor are staged side by side (2 x 36 864 and 2 x 32 768 elements of the 73 888)
-        constexpr int W3L = 9 * 4096, W2L = 16 * 2048;
-#pragma unroll
-        for (int i = 0; i < 18; ++i) {
-            *reinterpret_cast<u32x4*>(lds + (i >> 1) * 4096 + ((i & 1) ? l3b : l3a)) = r3h[i];
-            *reinterpret_cast<u32x4*>(lds + W3L + (i >> 1) * 4096 + ((i & 1) ? l3b : l3a)) = r3l[i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 18; ++ks) {
-            wf3h[ks] = read_frag<true, 64, 32>(lds + (ks >> 1) * 4096, wave * 16, ks & 1, lane);
-            wf3l[ks] = read_frag<true, 64, 32>(lds + W3L + (ks >> 1) * 4096, wave * 16, ks & 1, lane);
-        }
-        STACK_STAMP(a.prof, 0, 1)
-        {   // this image's inputs go out behind the weights (they are consumed after the staging)
-            const u32x4* s1 = reinterpret_cast<const u32x4*>(a.a1 + (long)img * 400 * 32);
-            const u32x4* s2 = reinterpret_cast<const u32x4*>(a.a2 + (long)img * 81 * 64);
-            const u32x4* s3 = reinterpret_cast<const u32x4*>(a.da3 + (long)img * 49 * 64);
-            const u32x4* s3l = reinterpret_cast<const u32x4*>(a.da3 + a.da3_plane + (long)img * 49 * 64);
-#pragma unroll
-            for (int i = 0; i < 7; ++i) { int t = tid + i * 256; i1[i] = s1[t < 1600 ? t : 0]; }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { int t = tid + i * 256; i2[i] = s2[t < 648 ? t : 0]; }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) { int t = tid + i * 256; i3h[i] = s3[t < 392 ? t : 0]; i3l[i] = s3l[t < 392 ? t : 0]; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            *reinterpret_cast<u32x4*>(lds + i * 2048 + l2) = r2h[i];
-            *reinterpret_cast<u32x4*>(lds + W2L + i * 2048 + l2) = r2l[i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {       // t = (a * 2 + b) * 2 + half
-            int ta = t >> 2, tb = (t >> 1) & 1, half = t & 1;
-            int tap = (py + 2 * ta) * 4 + (px + 2 * tb);
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                wf2h[t][nb] = read_frag<true, 32, 32>(lds + tap * 2048, nb * 16, half, lane);
-                wf2l[t][nb] = read_frag<true, 32, 32>(lds + W2L + tap * 2048, nb * 16, half, lane);
-            }
-        }
-        __syncthreads();
+    for (int ks = 0; ks < 18; ++ks) {       // tap = ks / 2, o half = ks % 2
+        const bf16_t* q = w3src + (ks >> 1) * 64 * 64 + (ks & 1) * 32;
+        wf3h[ks] = *reinterpret_cast<const bf16x8*>(q);
+        wf3l[ks] = *reinterpret_cast<const bf16x8*>(q + a.w_plane);
     }
+    STACK_STAMP(a.prof, 0, 1)
+    {
+        const u32x4* s1 = reinterpret_cast<const u32x4*>(a.a1 + (long)img * 400 * 32);
+        const u32x4* s2 = reinterpret_cast<const u32x4*>(a.a2 + (long)img * 81 * 64);
+        const u32x4* s3 = reinterpret_cast<const u32x4*>(a.da3 + (long)img * 49 * 64);
+        const u32x4* s3l = reinterpret_cast<const u32x4*>(a.da3 + a.da3_plane + (long)img * 49 * 64);
 #pragma unroll
-    for (int ks = 0; ks < 18; ++ks) { pin_agpr(wf3h[ks]); pin_agpr(wf3l[ks]); }
+        for (int i = 0; i < 7; ++i) { int t = tid + i * 256; i1[i] = s1[t < 1600 ? t : 0]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { int t = tid + i * 256; i2[i] = s2[t < 648 ? t : 0]; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { int t = tid + i * 256; i3h[i] = s3[t < 392 ? t : 0]; i3l[i] = s3l[t < 392 ? t : 0]; }
+    }
+    // fragment (t, nb) of conv2^T: t = (a * 2 + b) * 2 + o half, tap = (py + 2a) * 4 + px + 2b, channels 16 nb + l15
+    auto w2_frag = [&](int t, int nb, long plane) {
+        const int ta = t >> 2, tb = (t >> 1) & 1, half = t & 1;
+        const int tap = (py + 2 * ta) * 4 + (px + 2 * tb);
+        return *reinterpret_cast<const bf16x8*>(w2src + plane + (long)(tap * 32 + nb * 16) * 64 + half * 32);
+    };
     STACK_STAMP(a.prof, 0, 2)
     // the four grids start out all zero; the image only writes their interiors
     for (int t = tid; t < (DX_LDS_ELEMS - DX_A2H) / 8; t += 256)
         *reinterpret_cast<uint4*>(lds + DX_A2H + t * 8) = make_uint4(0, 0, 0, 0);
 
-    int in1[7], in2[3], in3[2];
-    int ld3[NRB3], st3[NRB3], ld2[NRB2], st2[NRB2];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         int t = tid + i * 256;
@@ -1615,6 +1580,8 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     __syncthreads();
 
     STACK_STAMP(a.prof, 0, 3)
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks) { pin_agpr(wf3h[ks]); pin_agpr(wf3l[ks]); }
     // ---- conv3^T: da2[(iy,ix)][c] = sum_{tap,o} w3[o][tap][c] da3[(iy-ky, ix-kx)][o], times relu'(a2); a unit is a
     // third (6 k-steps) of a row block's reduction
     {
@@ -1661,6 +1628,10 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
             if (third == 0 && rb > 0) { if (rb & 1) store(ca, rb - 1); else store(cb, rb - 1); }
             STACK_SCHED(18, 2, 3, 3)
             __builtin_amdgcn_sched_barrier(0);
+            if (u < 16) {       // two of conv2^T's 32 weight fragments per unit, under the MFMAs
+                wf2h[u >> 1][u & 1] = w2_frag(u >> 1, u & 1, 0);
+                wf2l[u >> 1][u & 1] = w2_frag(u >> 1, u & 1, a.w_plane);
+            }
         }
         if ((NRB3 - 1) & 1) store(cb, NRB3 - 1); else store(ca, NRB3 - 1);
     }
@@ -2213,16 +2184,17 @@ PDA_EXPORT void pda_cnn_dgrad_stack(const void* da3, const void* a2, const void*
 }
 
 // the chain at fp32 precision: da3 / da2 / da1 and the weights as (hi, lo) planes, a2 / a1 hi planes (relu masks)
-// frames != null: the launch also writes conv1's weight gradient, one slab slice (ws1 / bs1 floats apart) per image
+// w3t / w2t: the TRANSPOSED weight shadows [(tap, c)][o].  frames != null: the launch also writes conv1's weight
+// gradient, one slab slice (ws1 / bs1 floats apart) per image
 PDA_EXPORT void pda_cnn_dgrad_stack_x3(const void* da3, long da3_plane, const void* a2, const void* a1,
-                                       const void* w3, const void* w2, long w_plane, void* da2, long da2_plane,
+                                       const void* w3t, const void* w2t, long w_plane, void* da2, long da2_plane,
                                        void* da1, long da1_plane, int batch, const void* frames, const void* idx,
                                        void* gw1, void* gb1, long ws1, long bs1, float scale1, hipStream_t stream) {
-    DgradStackX3Args a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3,
-                          (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch, da3_plane, w_plane, da2_plane, da1_plane,
+    DgradStackX3Args a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3t,
+                          (const bf16_t*)w2t, (bf16_t*)da2, (bf16_t*)da1, batch, da3_plane, w_plane, da2_plane, da1_plane,
                           g_stack_prof, (const uint8_t*)frames, (const int*)idx, (float*)gw1, (float*)gb1, ws1, bs1,
                           scale1};
-    static_assert(DX_LDS_ELEMS >= 9 * 4096 && DX_LDS_ELEMS * 2 <= 160 * 1024, "weight staging / LDS budget");
+    static_assert(DX_LDS_ELEMS * 2 <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_x3_kernel<false>),

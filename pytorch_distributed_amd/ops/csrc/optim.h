@@ -16,7 +16,12 @@
 // hyper (device floats): lr, beta1, beta2, eps, weight_decay, clip, grad_scale
 // step: number of updates including this one (bumped earlier in the step, see dqn_head_kernel / pda_tick)
 // ----------------------------------------------------------------------------
-struct SegEntry { int start, count, cols, C, P, shadow_off, shadow_ld, flags; };
+// tr_ld > 0: the segment also keeps a TRANSPOSED copy of its shadow, element (row, q) at shadow[tr_off + q * tr_ld + row]
+// (+ the lo plane): the conv data-gradient kernels read w[o][(tap, c)] as fragments with the output channel o as the
+// reduction index, i.e. 8 consecutive o of one (tap, c) -- one 16-byte load from this copy instead of a transposition
+// of the whole tensor through LDS at the start of every launch.  Written wherever the shadow is (every optimizer
+// path and the Polyak / refresh kernel), so it cannot go stale.
+struct SegEntry { int start, count, cols, C, P, shadow_off, shadow_ld, flags, tr_off, tr_ld; };
 
 // kernel-order element j of segment s -> index of its fp32 master
 __device__ __forceinline__ long master_index(const SegEntry& s, int j, long* shadow_idx) {
@@ -67,6 +72,16 @@ __device__ __forceinline__ void put_shadow(bf16_t* shadow, long si, float w, lon
     bf16_t h = f2bf(w);
     shadow[si] = h;
     if (plane) shadow[si + plane] = f2bf(w - bf2f(h));
+}
+// the transposed copy of shadow element (row, q) of segment s (see SegEntry)
+__device__ __forceinline__ void put_tr(bf16_t* shadow, const SegEntry& s, int row, int q, float w, long plane) {
+    if (s.tr_ld > 0) put_shadow(shadow, (long)s.tr_off + (long)q * s.tr_ld + row, w, plane);
+}
+__device__ __forceinline__ void put_tr_elem(bf16_t* shadow, const SegEntry& s, int e, float w, long plane) {
+    if (s.tr_ld > 0) {
+        int row = e / s.cols;
+        put_shadow(shadow, (long)s.tr_off + (long)(e - row * s.cols) * s.tr_ld + row, w, plane);
+    }
 }
 
 #define OPT_CHUNK 2048      // elements per block (flat chunks)
@@ -214,6 +229,10 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
                         *reinterpret_cast<uint2*>(shadow + x.shadow_plane + sbase0 + q) =
                             make_uint2(pack2bf(r0, r1), pack2bf(r2, r3));
                     }
+                    if (s.tr_ld > 0) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) put_tr(shadow, s, r, q + k, pq[k], x.shadow_plane);
+                    }
                 }
             }
             __syncthreads();
@@ -255,6 +274,7 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
             pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
             row[c * pitch + pp] = pi; m[i] = mi; v[i] = vi;
             put_shadow(shadow, sbase + q, pi, x.shadow_plane);
+            put_tr(shadow, s, r, q, pi, x.shadow_plane);
         }
         __syncthreads();
         for (int i = threadIdx.x; i < s.cols; i += 256) {
@@ -298,7 +318,7 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
             float vi = b2 * v[i] + (1.f - b2) * gi * gi;
             pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
             p[ip] = pi; m[i] = mi; v[i] = vi;
-            if (si >= 0) put_shadow(shadow, si, pi, x.shadow_plane);
+            if (si >= 0) { put_shadow(shadow, si, pi, x.shadow_plane); put_tr_elem(shadow, s, e, pi, x.shadow_plane); }
             put_extras(x, shadow, s, ch.x, e, ip, si, pi);
         }
         return;
@@ -315,7 +335,7 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
         float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
         p[ip] = pi; m[i] = mi; v[i] = vi;
-        if (si >= 0) put_shadow(shadow, si, pi, x.shadow_plane);
+        if (si >= 0) { put_shadow(shadow, si, pi, x.shadow_plane); put_tr_elem(shadow, s, e, pi, x.shadow_plane); }
         put_extras(x, shadow, s, ch.x, e, ip, si, pi);
     }
 }

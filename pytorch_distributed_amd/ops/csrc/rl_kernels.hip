@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void polyak_kernel(float* tgt, const float* sr
         float t = tgt[i] + tau * (src[i] - tgt[i]);
         if (tau >= 1.f) t = src[i];
         tgt[i] = t;
-        if (shadow && si >= 0) put_shadow(shadow, si, t, shadow_plane);
+        if (shadow && si >= 0) { put_shadow(shadow, si, t, shadow_plane); put_tr_elem(shadow, s, e, t, shadow_plane); }
     }
 }
 

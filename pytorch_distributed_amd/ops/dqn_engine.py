@@ -159,10 +159,14 @@ class CnnWeights(object):
         segs = {name: (off, shape) for name, off, shape in model.param_segments()}
         g = geom
         shadow_shapes = [(32, g.K1, 1, g.K1), (64, g.K2, 32, 16), (64, g.K3, 64, 9), (g.HID, g.F, 64, g.P3)]
-        total = sum(r * c for r, c, _, _ in shadow_shapes)
+        main = sum(r * c for r, c, _, _ in shadow_shapes)
+        # conv2 / conv3 also keep a transposed copy [(tap, c)][o] behind the main shadows (csrc/optim.h SegEntry): the
+        # data-gradient kernels read their weight fragments from it with plain 16-byte loads
+        tr_offs = {1: main, 2: main + shadow_shapes[1][0] * shadow_shapes[1][1]}
+        total = tr_offs[2] + shadow_shapes[2][0] * shadow_shapes[2][1]
         self.shadow = torch.zeros(total * (2 if self.split else 1), dtype=BF16, device=dev)
         self.shadow_plane = total if self.split else 0
-        entries, self.w, self.b, self.off = [], [], [], {}
+        entries, self.w, self.b, self.off, self.wT = [], [], [], {}, {}
         soff = 0
         for li, layer in enumerate(self.ORDER):
             woff, wshape = segs[layer + ".weight"]
@@ -179,6 +183,12 @@ class CnnWeights(object):
                 if self.split:      # hi-plane view + the offset of its lo plane, as the x3 kernels take operands
                     wv = _PlaneView(wv, self.shadow[total + soff:total + soff + rows * cols].view(rows, cols))
                 self.w.append(wv)
+                if li in tr_offs:
+                    ent.update(tr_off=tr_offs[li], tr_ld=rows)
+                    tv = self.shadow[tr_offs[li]:tr_offs[li] + rows * cols].view(cols, rows)
+                    if self.split:
+                        tv = _PlaneView(tv, self.shadow[total + tr_offs[li]:total + tr_offs[li] + rows * cols].view(cols, rows))
+                    self.wT[li] = tv
                 soff += rows * cols
             else:
                 self.w.append(self.flat[woff:woff + wn].view(wshape))       # fc2 stays fp32
@@ -571,7 +581,7 @@ class DqnCnnEngine(object):
                                    act=nn.ACT_RELU)
             if nn.x3_cnn_dgrad_stack_supported(g.H, g.W, g.C):
                 # both conv data gradients in one launch (per image, every plane LDS-resident)
-                nn.x3_cnn_dgrad_stack(a.da3, a.a2[0].hi, a.a1[0].hi, on.w[2], on.w[1], a.da2, a.da1, B,
+                nn.x3_cnn_dgrad_stack(a.da3, a.a2[0].hi, a.a1[0].hi, on.wT[2], on.wT[1], a.da2, a.da1, B,
                                       w1=(s0, idx, w1s, b1s, 1.0 / self.norm_val) if self.x3_fuse_w1 else None)
             else:
                 nn.x3_conv_dgrad(a.da3, on.w[2], a.a2[0].hi, a.da2, B, g.H2, g.W2, 64, 3, 3, 1, 64, act=nn.ACT_RELU)

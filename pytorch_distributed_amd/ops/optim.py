@@ -30,14 +30,15 @@ def _stream():
 
 class SegmentTable(object):
     """Device tables describing each parameter tensor of a flat buffer.
-    entries: dicts with start, count, cols, C, P, shadow_off, shadow_ld, shadow(bool)."""
+    entries: dicts with start, count, cols, C, P, shadow_off, shadow_ld, shadow(bool), tr_off, tr_ld."""
 
     def __init__(self, entries, device):
         rows, chunks = [], []
         for si, e in enumerate(entries):
             rows.append([e["start"], e["count"], e.get("cols", e["count"]), e.get("C", 1),
                          e.get("P", e.get("cols", e["count"])), e.get("shadow_off", 0), e.get("shadow_ld", 0),
-                         (1 if e.get("shadow", False) else 0) | (2 if e.get("fine", False) else 0)])
+                         (1 if e.get("shadow", False) else 0) | (2 if e.get("fine", False) else 0),
+                         e.get("tr_off", 0), e.get("tr_ld", 0)])     # transposed shadow copy (csrc/optim.h SegEntry)
             cols, C, P = rows[-1][2], rows[-1][3], rows[-1][4]
             row_mode = bool(e.get("shadow", False)) and C > 1 and (P | 1) * C <= OPT_ROW_LDS
             step = cols if row_mode else (64 if e.get("fine", False) else OPT_CHUNK)

@@ -176,7 +176,8 @@ def test_x3_cnn_dgrad_stack(nn, batch):
     pre3.backward(da3.double())
     ref_da2 = a2d.grad * (a2d.detach() > 0)         # gradient w.r.t. conv2's pre-activation
     ref_da1 = a1d.grad * (a1d.detach() > 0)         # ... conv1's pre-activation
-    flat = [w2.permute(0, 2, 3, 1).reshape(64, -1).contiguous(), w3.permute(0, 2, 3, 1).reshape(64, -1).contiguous()]
+    # the kernel reads the TRANSPOSED shadows [(tap, c)][o]
+    flat = [w2.permute(2, 3, 1, 0).reshape(-1, 64).contiguous(), w3.permute(2, 3, 1, 0).reshape(-1, 64).contiguous()]
     total = sum(f.numel() for f in flat)
     buf = torch.zeros(2, total, dtype=torch.bfloat16, device="cuda")
     views, off = [], 0

@@ -35,6 +35,7 @@ def shadow(shapes):
 mem = torch.randint(0, 256, (4096, 4, 84, 84), dtype=torch.uint8, device=dev)
 idx = torch.randint(0, 4096, (B,), dtype=torch.int32, device=dev)
 nets = [shadow([(32, 256), (64, 512), (64, 576)]) for _ in range(2)]
+wT = shadow([(512, 64), (576, 64)])
 bs = [torch.zeros(32, device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev)]
 a1 = [nn.Planes(B * 400, 32, device=dev), None]
 a2 = [nn.Planes(B * 81, 64, device=dev), None]
@@ -49,13 +50,13 @@ def fwd():
 
 
 def bwd():
-    nn.x3_cnn_dgrad_stack(da3, a2[0].hi, a1[0].hi, nets[0][0][2], nets[0][0][1], da2, da1, B)
+    nn.x3_cnn_dgrad_stack(da3, a2[0].hi, a1[0].hi, wT[0][1], wT[0][0], da2, da1, B)
 
 
 for name, fn, labels in (
         ("forward stack", fwd, ["start", "loads issued + offsets", "patch committed", "conv1", "-", "a1 out + pins",
                                 "conv2", "-", "a2 out + pins", "conv3"]),
-        ("dgrad stack", bwd, ["start", "w3 hi staged", "all weights staged", "grids + inputs", "conv3^T", "da2 out",
+        ("dgrad stack", bwd, ["start", "w3 fragments issued", "inputs issued", "grids + inputs", "conv3^T", "da2 out",
                               "conv2^T", "da1 out"])):
     prof = torch.zeros(128, dtype=torch.int64, device=dev)
     for rep in range(3):
