@@ -1472,7 +1472,9 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     constexpr int P1 = 400, P2 = 81, P3 = 49, NRB3 = 6, NRB2 = 7;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, l15 = lane & 15;
-    const int img = blockIdx.x;
+    // two workgroups per image: both run conv3^T (da2 is needed whole), workgroup h = blockIdx.x & 1 then owns the
+    // a1 / da1 rows of parity h -- the parity classes (h, 0) and (h, 1) of conv2^T and those pixels' share of dW1
+    const int img = blockIdx.x >> 1, hh = blockIdx.x & 1;
     constexpr int FH = 84, FW = 84;
     constexpr long frame_bytes = 4L * FH * FW;
     long f0 = 0;
@@ -1484,12 +1486,13 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     // straight from the transposed shadows the optimizer keeps: 16 bytes per lane and fragment, no staging.  (Transposed
     // through LDS at the start of the launch, as the bf16 kernel does, the four tensors cost 8 barriers and 10 k cycles
     // before the first MFMA.)
-    u32x4 i1[7], i2[3], i3h[2], i3l[2];
-    int in1[7], in2[3], in3[2];
-    int ld3[NRB3], st3[NRB3], ld2[NRB2], st2[NRB2];
+    constexpr int NRB2W = 4;             // conv2^T row blocks per wave: wave = (px, part), part 0 -> blocks 0-3, 1 -> 4-6
+    u32x4 i1[4], i2[3], i3h[2], i3l[2];
+    int in1[4], g1[4], in2[3], in3[2];
+    int ld3[NRB3], st3[NRB3], ld2[NRB2W], st2[NRB2W];
     bf16x8 wf3h[18], wf3l[18];      // conv3^T: this wave's 16 input channels; k-step = (tap, o half)
     bf16x8 wf2h[8][2], wf2l[8][2];  // conv2^T: this wave's parity class; (tap a,b ; o half) x 2 channel blocks
-    const int py = wave >> 1, px = wave & 1;
+    const int py = hh, px = wave & 1, part = wave >> 1;
     const bf16_t* w3src = a.w3t + (long)(wave * 16 + l15) * 64 + g4 * 8;
     const bf16_t* w2src = a.w2t + (long)l15 * 64 + g4 * 8;
 #pragma unroll
@@ -1499,13 +1502,22 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         wf3l[ks] = *reinterpret_cast<const bf16x8*>(q + a.w_plane);
     }
     STACK_STAMP(a.prof, 0, 1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {       // chunk t of this workgroup's 200 pixels (rows of parity py) x 4 x 16 bytes
+        int t = tid + i * 256;
+        t = t < 800 ? t : 0;
+        const int pp = t >> 2, p = (2 * (pp / 20) + py) * 20 + pp % 20;
+        in1[i] = p * D1_CP + (t & 3) * 8;
+        g1[i] = p * 4 + (t & 3);
+        asm volatile("" : "+v"(in1[i]), "+v"(g1[i]));
+    }
     {
         const u32x4* s1 = reinterpret_cast<const u32x4*>(a.a1 + (long)img * 400 * 32);
         const u32x4* s2 = reinterpret_cast<const u32x4*>(a.a2 + (long)img * 81 * 64);
         const u32x4* s3 = reinterpret_cast<const u32x4*>(a.da3 + (long)img * 49 * 64);
         const u32x4* s3l = reinterpret_cast<const u32x4*>(a.da3 + a.da3_plane + (long)img * 49 * 64);
 #pragma unroll
-        for (int i = 0; i < 7; ++i) { int t = tid + i * 256; i1[i] = s1[t < 1600 ? t : 0]; }
+        for (int i = 0; i < 4; ++i) i1[i] = s1[g1[i]];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { int t = tid + i * 256; i2[i] = s2[t < 648 ? t : 0]; }
 #pragma unroll
@@ -1522,13 +1534,6 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     for (int t = tid; t < (DX_LDS_ELEMS - DX_A2H) / 8; t += 256)
         *reinterpret_cast<uint4*>(lds + DX_A2H + t * 8) = make_uint4(0, 0, 0, 0);
 
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        int t = tid + i * 256;
-        t = t < P1 * 4 ? t : 0;
-        in1[i] = (t >> 2) * D1_CP + (t & 3) * 8;
-        asm volatile("" : "+v"(in1[i]));
-    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         int t = tid + i * 256;
@@ -1555,8 +1560,8 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         asm volatile("" : "+v"(ld3[rb]), "+v"(st3[rb]));
     }
 #pragma unroll
-    for (int rb = 0; rb < NRB2; ++rb) {
-        int q = rb * 16 + l15;
+    for (int rb = 0; rb < NRB2W; ++rb) {
+        int q = (part * NRB2W + rb) * 16 + l15;
         q = q < 100 ? q : 0;
         int iy2 = q / 10, ix2 = q - 10 * iy2;
         ld2[rb] = DX_A2H + (iy2 + 1) * D2_RP + (ix2 + 1) * D2_CP + g4 * 8;
@@ -1566,8 +1571,8 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();                    // grids zeroed
 #pragma unroll
-    for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(lds + in1[i]) = i1[i];
-    if (tid < P1 * 4 - 1536) *reinterpret_cast<u32x4*>(lds + in1[6]) = i1[6];
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(lds + in1[i]) = i1[i];
+    if (tid < 800 - 768) *reinterpret_cast<u32x4*>(lds + in1[3]) = i1[3];
     *reinterpret_cast<u32x4*>(lds + in2[0]) = i2[0];
     *reinterpret_cast<u32x4*>(lds + in2[1]) = i2[1];
     if (tid < P2 * 8 - 512) *reinterpret_cast<u32x4*>(lds + in2[2]) = i2[2];
@@ -1642,7 +1647,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         uint4* dstl = reinterpret_cast<uint4*>(a.da2 + a.da2_plane + (long)img * P2 * 64);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            if (i < 2 || tid < P2 * 8 - 512) {
+            if (hh == 0 && (i < 2 || tid < P2 * 8 - 512)) {     // both workgroups of the pair hold the same da2
                 dst[tid + i * 256] = *reinterpret_cast<const uint4*>(lds + in2[i]);
                 dstl[tid + i * 256] = *reinterpret_cast<const uint4*>(lds + in2[i] + (DX_A2L - DX_A2H));
             }
@@ -1680,7 +1685,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
             }
         };
         auto store = [&](const f32x4 (&c0)[3], const f32x4 (&c1)[3], int rb) {
-            if (rb * 16 + l15 < 100) {
+            if ((part * NRB2W + rb) * 16 + l15 < 100) {
                 uint2* cell = reinterpret_cast<uint2*>(lds + st2[rb]);      // this class's pixels only
                 uint2* celll = reinterpret_cast<uint2*>(lds + st2[rb] + DX_A1L);
                 uint2 h, l;
@@ -1695,14 +1700,14 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         load(xah, xal, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rb = 0; rb < NRB2; ++rb) {
-            if (rb + 1 < NRB2) { if (rb & 1) load(xah, xal, rb + 1); else load(xbh, xbl, rb + 1); }
+        for (int rb = 0; rb < NRB2W; ++rb) {        // (part 1's fourth block is all padding: computed, never stored)
+            if (rb + 1 < NRB2W) { if (rb & 1) load(xah, xal, rb + 1); else load(xbh, xbl, rb + 1); }
             if (rb & 1) mul(xbh, xbl, cb0, cb1); else mul(xah, xal, ca0, ca1);
             if (rb > 0) { if (rb & 1) store(ca0, ca1, rb - 1); else store(cb0, cb1, rb - 1); }
             STACK_SCHED(48, 1, 3, 2)
             __builtin_amdgcn_sched_barrier(0);
         }
-        if ((NRB2 - 1) & 1) store(cb0, cb1, NRB2 - 1); else store(ca0, ca1, NRB2 - 1);
+        if ((NRB2W - 1) & 1) store(cb0, cb1, NRB2W - 1); else store(ca0, ca1, NRB2W - 1);
     }
     STACK_STAMP(a.prof, 0, 6)
     __syncthreads();                    // the a1 rows now hold da1 (hi), the rows behind them its lo plane
@@ -1710,18 +1715,18 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         uint4* dst = reinterpret_cast<uint4*>(a.da1 + (long)img * P1 * 32);
         uint4* dstl = reinterpret_cast<uint4*>(a.da1 + a.da1_plane + (long)img * P1 * 32);
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            if (i < 6 || tid < P1 * 4 - 1536) {
-                dst[tid + i * 256] = *reinterpret_cast<const uint4*>(lds + in1[i]);
-                dstl[tid + i * 256] = *reinterpret_cast<const uint4*>(lds + in1[i] + DX_A1L);
+        for (int i = 0; i < 4; ++i) {           // this workgroup's rows
+            if (i < 3 || tid < 800 - 768) {
+                dst[g1[i]] = *reinterpret_cast<const uint4*>(lds + in1[i]);
+                dstl[g1[i]] = *reinterpret_cast<const uint4*>(lds + in1[i] + DX_A1L);
             }
         }
     }
     STACK_STAMP(a.prof, 0, 7)
     if constexpr (W1) {
         // ---- conv1 weight gradient: dW1[o][(c, ky, kx)] = sum_px da1[px][o] patch[c][4 oy + ky][4 ox + kx];
-        // wave w = kernel channel w, 13 chunks of 32 pixels; pixels >= 400 read a zeroed strip behind the patch
-        constexpr int P1 = 400;
+        // wave w = kernel channel w; this workgroup's 200 pixels in 7 chunks of 32 (pad pixels read a zeroed strip
+        // behind the patch)
         bf16_t* patch = lds + DX_A2H;
         constexpr int ZOFF = DX_A2H + 4 * FH * FW;
         static_assert(ZOFF + 64 <= DX_LDS_ELEMS, "zero strip");
@@ -1743,18 +1748,19 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
 #pragma unroll
         for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
         auto load = [&](bf16x8 (&fa)[4], bf16x8 (&fb)[4], int ch) {
-            int p0 = ch * 32 + 8 * tg + tq, p1 = p0 + 4;
-            const bool in0 = p0 < P1, in1 = p1 < P1;
-            int a0 = (in0 ? p0 * D1_CP : ZOFF) + 4 * tp, a1o = (in1 ? p1 * D1_CP : ZOFF) + 4 * tp;
+            const int pp0 = ch * 32 + 8 * tg + tq, pp1 = pp0 + 4;
+            const bool in0 = pp0 < 200, in1 = pp1 < 200;
+            const int y0 = in0 ? 2 * (pp0 / 20) + py : 0, x0 = in0 ? pp0 % 20 : 0;
+            const int y1 = in1 ? 2 * (pp1 / 20) + py : 0, x1 = in1 ? pp1 % 20 : 0;
+            int a0 = (in0 ? (y0 * 20 + x0) * D1_CP : ZOFF) + 4 * tp, a1o = (in1 ? (y1 * 20 + x1) * D1_CP : ZOFF) + 4 * tp;
             int l0 = in0 ? DX_A1L : 0, l1 = in1 ? DX_A1L : 0;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 fa[i] = tr_frag(lds + a0 + i * 16, lds + a1o + i * 16);
                 fa[2 + i] = tr_frag(lds + a0 + l0 + i * 16, lds + a1o + l1 + i * 16);
             }
-            int q0 = in0 ? p0 : 0, q1 = in1 ? p1 : 0;
-            const bf16_t* b0 = patch + (4 * (q0 / 20)) * FW + 4 * (q0 % 20);
-            const bf16_t* b1 = patch + (4 * (q1 / 20)) * FW + 4 * (q1 % 20);
+            const bf16_t* b0 = patch + (4 * y0) * FW + 4 * x0;
+            const bf16_t* b1 = patch + (4 * y1) * FW + 4 * x1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) fb[j] = tr_frag(b0 + boff[j], b1 + boff[j]);
         };
@@ -1775,13 +1781,13 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
         load(fa0, fb0, 0);
 #pragma unroll 1
-        for (int ch = 0; ch < 12; ch += 2) {        // chunks ch, ch + 1; fragments one chunk ahead
+        for (int ch = 0; ch < 6; ch += 2) {         // chunks ch, ch + 1; fragments one chunk ahead
             load(fa1, fb1, ch + 1);
             mma(fa0, fb0);
             load(fa0, fb0, ch + 2);
             mma(fa1, fb1);
         }
-        mma(fa0, fb0);                              // chunk 12
+        mma(fa0, fb0);                              // chunk 6
         // [32][256] tile -> slab slice blockIdx.x (kernel layout == PyTorch's (c, ky, kx))
         float* dw = a.gw1 + (long)blockIdx.x * a.ws1;
 #pragma unroll
@@ -2185,7 +2191,7 @@ PDA_EXPORT void pda_cnn_dgrad_stack(const void* da3, const void* a2, const void*
 
 // the chain at fp32 precision: da3 / da2 / da1 and the weights as (hi, lo) planes, a2 / a1 hi planes (relu masks)
 // w3t / w2t: the TRANSPOSED weight shadows [(tap, c)][o].  frames != null: the launch also writes conv1's weight
-// gradient, one slab slice (ws1 / bs1 floats apart) per image
+// gradient, TWO slab slices (ws1 / bs1 floats apart) per image (one per workgroup)
 PDA_EXPORT void pda_cnn_dgrad_stack_x3(const void* da3, long da3_plane, const void* a2, const void* a1,
                                        const void* w3t, const void* w2t, long w_plane, void* da2, long da2_plane,
                                        void* da1, long da1_plane, int batch, const void* frames, const void* idx,
@@ -2204,9 +2210,9 @@ PDA_EXPORT void pda_cnn_dgrad_stack_x3(const void* da3, long da3_plane, const vo
         attr_set = true;
     }
     if (frames)
-        hipLaunchKernelGGL(cnn_dgrad_stack_x3_kernel<true>, dim3(batch), dim3(256), (size_t)DX_LDS_ELEMS * 2, stream, a);
+        hipLaunchKernelGGL(cnn_dgrad_stack_x3_kernel<true>, dim3(2 * batch), dim3(256), (size_t)DX_LDS_ELEMS * 2, stream, a);
     else
-        hipLaunchKernelGGL(cnn_dgrad_stack_x3_kernel<false>, dim3(batch), dim3(256), (size_t)DX_LDS_ELEMS * 2, stream, a);
+        hipLaunchKernelGGL(cnn_dgrad_stack_x3_kernel<false>, dim3(2 * batch), dim3(256), (size_t)DX_LDS_ELEMS * 2, stream, a);
 }
 
 // same, plus conv1's weight gradient from uint8 frames (slab slice per workgroup: pda_cnn_dgrad_stack_slices(batch))

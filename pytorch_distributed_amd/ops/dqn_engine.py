@@ -383,7 +383,7 @@ class DqnCnnEngine(object):
         # conv1's weight gradient as a tail of the dgrad stack launch (da1 still in LDS)
         self.fuse_w1 = (bool(self.acts.stack_dgrad) and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32)
                         and os.environ.get("PDA_FUSE_W1", "1") != "0" and not x3)
-        # the same for the fp32-precision dgrad stack (one workgroup = one slab slice per image: small batches)
+        # the same for the fp32-precision dgrad stack (two workgroups = two slab slices per image: small batches)
         self.x3_fuse_w1 = (x3 and nn.x3_cnn_dgrad_stack_supported(g.H, g.W, g.C) and self.B <= 256
                            and os.environ.get("PDA_FUSE_W1", "1") != "0")
         self._plan_wgrads()
@@ -442,7 +442,7 @@ class DqnCnnEngine(object):
                 if self.fuse_w1 and not self.x3:
                     ns = nn.cnn_dgrad_stack_slices(B)   # computed by the dgrad stack launch itself
                 if self.x3_fuse_w1:
-                    ns = B                              # fp32-precision dgrad stack: one slice per image
+                    ns = 2 * B                          # fp32-precision dgrad stack: one slice per workgroup, two per image
             plans.append((li, O, K, ks, ns))
         self.wg_plan = plans
         total = sum(ns * (O * K + O) for _, O, K, _, ns in plans)

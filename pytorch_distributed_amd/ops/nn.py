@@ -520,8 +520,8 @@ def x3_cnn_dgrad_stack(da3, a2_hi, a1_hi, w3t, w2t, da2, da1, batch, w1=None):
     """da3 -> da2 -> da1 on split planes in one launch (cnn_dgrad_stack_x3_kernel): da* as Planes, the weights as the
     TRANSPOSED split shadows [(tap, c)][o] the optimizer keeps (CnnWeights.wT; both in one shadow buffer: one plane
     offset), a2 / a1 the hi planes of the forward activations.
-    w1 = (frames uint8, idx int32 or None, gw slab [batch][32*256], gb slab [batch][32], scale): the same launch also
-    leaves conv1's weight / bias gradient, one slab slice per image."""
+    w1 = (frames uint8, idx int32 or None, gw slab [2 * batch][32*256], gb slab [2 * batch][32], scale): the same launch
+    also leaves conv1's weight / bias gradient, one slab slice per workgroup (two workgroups share an image)."""
     assert _plane(w3t) == _plane(w2t)
     frames, idx, gw, gb, scale = w1 if w1 is not None else (None, None, None, None, 1.0)
     _X().pda_cnn_dgrad_stack_x3(_ptr(da3), _plane(da3), _ptr(a2_hi), _ptr(a1_hi), _ptr(w3t), _ptr(w2t), _plane(w3t),

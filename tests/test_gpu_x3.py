@@ -196,11 +196,11 @@ def test_x3_cnn_dgrad_stack(nn, batch):
     nn.x3_cnn_dgrad_stack(planes_nhwc(nn, da3), a2_hi, a1_hi, views[1], views[0], da2, da1, batch)
     assert rel(from_nhwc(da2.value(), batch, 9, 9, 64), ref_da2) < TOL
     assert rel(from_nhwc(da1.value(), batch, 20, 20, 32), ref_da1) < TOL
-    # the same launch with conv1's weight gradient as its tail: one slab slice per image, frames through an index
+    # the same launch with conv1's weight gradient as its tail, frames through an index
     mem = torch.randint(0, 256, (40, 4, 84, 84), dtype=torch.uint8, device="cuda")
     idx = torch.randint(0, 40, (batch,), dtype=torch.int32, device="cuda")
-    gw = torch.full((batch, 32 * 256), 7.0, device="cuda")
-    gb = torch.full((batch, 32), 7.0, device="cuda")
+    gw = torch.full((2 * batch, 32 * 256), 7.0, device="cuda")      # one slab slice per workgroup, two per image
+    gb = torch.full((2 * batch, 32), 7.0, device="cuda")
     da2.full.fill_(9.0)
     da1.full.fill_(9.0)
     nn.x3_cnn_dgrad_stack(planes_nhwc(nn, da3), a2_hi, a1_hi, views[1], views[0], da2, da1, batch,

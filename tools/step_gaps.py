@@ -20,7 +20,7 @@ def main():
     rows = con.execute("select name, start, end from kernels order by start").fetchall()
     rows = rows[-2000:]
     names = [r[0] for r in rows]
-    first = "cnn_fwd_stack_kernel" if any("cnn_fwd_stack_kernel" in n for n in names) else names[0]
+    first = next((k for k in ("cnn_fwd_stack_x3_kernel", "cnn_fwd_stack_kernel") if any(k in n for n in names)), names[0])
     idx = [i for i, n in enumerate(names) if first in n]
     dur, gap, cnt = defaultdict(float), defaultdict(float), defaultdict(int)
     steps, total = 0, 0.0
