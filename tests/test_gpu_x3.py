@@ -443,9 +443,22 @@ def test_engine_fp32_precision_adam_keeps_split_shadows(nn):
     want = w2.permute(0, 2, 3, 1).reshape(64, -1)
     assert torch.equal(e.online.w[1].hi, pnn.pack_conv_weight(w2))
     assert rel(e.online.w[1].value(), want) < 2 ** -16
+    # the transposed copies [(tap, c)][o] the data-gradient stack reads follow every optimizer path bit for bit
+    for li in (1, 2):
+        assert torch.equal(e.online.wT[li].hi, e.online.w[li].hi.t().contiguous())
+        assert torch.equal(e.online.wT[li].lo, e.online.w[li].lo.t().contiguous())
     e.hard_target_update()
     assert torch.equal(e.target.flat, e.online.flat)
     assert torch.equal(e.target.shadow, e.online.shadow)
+    # ... also the vector row path (gradients given directly, as in a data-parallel step after the reduce launch)
+    # and a refresh from the master weights
+    e.adam.step(tick=True)
+    e.online.flat.mul_(1.25)
+    e.online.refresh()
+    torch.cuda.synchronize()
+    for li in (1, 2):
+        assert torch.equal(e.online.wT[li].hi, e.online.w[li].hi.t().contiguous())
+        assert torch.equal(e.online.wT[li].lo, e.online.w[li].lo.t().contiguous())
 
 
 def test_engine_fp32_precision_steps_from_hbm_replay_in_a_graph(nn):
