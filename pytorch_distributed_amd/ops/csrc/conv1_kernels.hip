@@ -1066,6 +1066,7 @@ struct DgradStackArgs {
     bf16_t* da2; bf16_t* da1; int batch;
     // optional tail (W1): conv1's weight gradient of the same image, from da1 while it is still in LDS
     const uint8_t* frames; const int* idx; float* gw1; float* gb1; long ws1, bs1; float scale1;
+    long long* prof;    // optional phase stamps of workgroup 0 (pda_cnn_stack_prof)
 };
 
 // LDS plan (bf16 elements).  da3 and a2 / da2 live in zero-bordered 11 x 11 grids, so every tap of the two
@@ -1126,6 +1127,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
     const int g4 = lane >> 4, l15 = lane & 15;
     const int G = gridDim.x;
 
+    STACK_STAMP(a.prof, 0, 0)
     DgradRegs in;
     int img = blockIdx.x;
     PatchRegs pr;
@@ -1170,6 +1172,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
         }
     }
     __syncthreads();
+    STACK_STAMP(a.prof, 0, 1)
     const int py = wave >> 1, px = wave & 1;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {       // t = (a * 2 + b) * 2 + half
@@ -1269,6 +1272,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
             f_nxt = frame_index(a.idx, img + 2 * G, a.batch);
         }
 
+        STACK_STAMP(a.prof, 0, 3)
         // ---- conv3^T: da2[(iy,ix)][c] = sum_{tap,o} w3[o][tap][c] da3[(iy-ky, ix-kx)][o], times relu'(a2).
         // Swapped product (weights as the A operand): a lane ends with 4 consecutive channels of one pixel.
         {
@@ -1311,6 +1315,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
             }
             if ((NRB3 - 1) & 1) store(cb0, cb1, NRB3 - 1); else store(ca0, ca1, NRB3 - 1);
         }
+        STACK_STAMP(a.prof, 0, 4)
         __syncthreads();                    // the a2 grid now holds da2
         {
             uint4* dst = reinterpret_cast<uint4*>(a.da2 + (long)img * P2 * 64);
@@ -1318,6 +1323,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
             dst[tid] = v0; dst[tid + 256] = v1;
             if (tid < P2 * 8 - 512) dst[tid + 512] = *reinterpret_cast<const uint4*>(lds + in2[2]);
         }
+        STACK_STAMP(a.prof, 0, 5)
         // ---- conv2^T for this wave's parity class: input pixel (2 iy2 + py, 2 ix2 + px), taps (py + 2a, px + 2b)
         // read da2 at (iy2 - a, ix2 - b); both 16-channel blocks of a1 per fragment
         {
@@ -1360,6 +1366,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
             }
             if ((NRB2 - 1) & 1) store(cb0, cb1, NRB2 - 1); else store(ca0, ca1, NRB2 - 1);
         }
+        STACK_STAMP(a.prof, 0, 6)
         __syncthreads();                    // the a1 rows now hold da1
         {
             uint4* dst = reinterpret_cast<uint4*>(a.da1 + (long)img * P1 * 32);
@@ -1370,6 +1377,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
             for (int i = 0; i < 6; ++i) dst[tid + i * 256] = v[i];
             if (tid < P1 * 4 - 1536) dst[tid + 1536] = *reinterpret_cast<const uint4*>(lds + in1[6]);
         }
+        STACK_STAMP(a.prof, 0, 7)
         if constexpr (W1) {
             // ---- conv1 weight gradient: dW1[o][(c, ky, kx)] += sum_px da1[px][o] patch[c][4 oy + ky][4 ox + kx];
             // 13 chunks of 32 pixels; pixels >= 400 read the (always zero) first border row of the a2 grid
@@ -1405,11 +1413,13 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
             mma(fa0, fb0);                              // chunk 12
         }
     };
+    STACK_STAMP(a.prof, 0, 2)
     if (img < a.batch) {
         process(img);
         if constexpr (MULTI)
             for (img += G; img < a.batch; img += G) process(img);
     }
+    STACK_STAMP(a.prof, 0, 8)
     if constexpr (W1) {
         // partial [32][256] tile -> slab slice blockIdx.x (kernel layout == PyTorch's (c, ky, kx))
         float* dw = a.gw1 + (long)blockIdx.x * a.ws1;
@@ -2162,6 +2172,7 @@ PDA_EXPORT void pda_cnn_fwd_stack_x3(const void* const* frames, const void* cons
 PDA_EXPORT int pda_cnn_dgrad_stack_supported(int H, int W, int C) { return (H == 84 && W == 84 && C == 4) ? 1 : 0; }
 
 static void launch_dgrad_stack(DgradStackArgs& a, hipStream_t stream) {
+    a.prof = g_stack_prof;
     const bool w1 = a.frames != nullptr;
     size_t lds = ((size_t)D_LDS_ELEMS + (w1 ? 4 * 84 * 84 : 0)) * 2;   // >= the 9 x 4096-element weight staging tiles
     static_assert(D_LDS_ELEMS >= 9 * 4096, "weight staging must fit the working set's LDS");
@@ -2185,7 +2196,8 @@ static void launch_dgrad_stack(DgradStackArgs& a, hipStream_t stream) {
 PDA_EXPORT void pda_cnn_dgrad_stack(const void* da3, const void* a2, const void* a1, const void* w3, const void* w2,
                                     void* da2, void* da1, int batch, hipStream_t stream) {
     DgradStackArgs a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3,
-                        (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch, nullptr, nullptr, nullptr, nullptr, 0, 0, 1.f};
+                        (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch, nullptr, nullptr, nullptr, nullptr, 0, 0, 1.f,
+                        nullptr};
     launch_dgrad_stack(a, stream);
 }
 
@@ -2222,7 +2234,7 @@ PDA_EXPORT void pda_cnn_dgrad_stack_w1(const void* da3, const void* a2, const vo
                                        void* gw1, void* gb1, long ws1, long bs1, float scale1, hipStream_t stream) {
     DgradStackArgs a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3,
                         (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch, (const uint8_t*)frames, (const int*)idx,
-                        (float*)gw1, (float*)gb1, ws1, bs1, scale1};
+                        (float*)gw1, (float*)gb1, ws1, bs1, scale1, nullptr};
     launch_dgrad_stack(a, stream);
 }
 

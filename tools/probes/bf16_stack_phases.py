@@ -28,3 +28,23 @@ names = ["loop top", "committed", "conv1 done", "barrier", "a1 out", "pinned", "
 print("bf16 forward stack, batch %d; prologue (cycles before the loop top): kernel entry %d, loads issued %d, w1 staged %d" % (B, p[10] - p[0], p[11] - p[0], p[12] - p[0]))
 for i, n in enumerate(names):
     print("   %-12s %8d %8d" % (n, p[i] - p[0], p[i] - p[max(i - 1, 0)]))
+
+# ---- data-gradient stack (+ conv1 weight gradient)
+da3 = torch.randn(B * 49, 64, device=dev).to(bf)
+da2 = torch.zeros_like(a2); da1 = torch.zeros_like(a1)
+ns = nn.cnn_dgrad_stack_slices(B)
+slab = torch.zeros(ns, 32 * 256, device=dev); bslab = torch.zeros(ns, 32, device=dev)
+for rep in range(3):
+    prof.zero_()
+    L.pda_cnn_stack_prof(ctypes.c_void_p(prof.data_ptr()))
+    nn.cnn_dgrad_stack(da3, a2, a1, w3, w2, da2, da1, B, w1=(mem, idx, slab, bslab, 1 / 255.))
+    torch.cuda.synchronize()
+    L.pda_cnn_stack_prof(ctypes.c_void_p(0))
+p = prof.cpu()[:16].tolist()
+names = ["start", "weights staged (LDS)", "fragments + offsets", "inputs committed", "conv3^T", "da2 out", "conv2^T",
+         "da1 out", "conv1 wgrad"]
+print("bf16 dgrad stack + conv1 wgrad, batch %d" % B)
+prev = p[0]
+for i, n in enumerate(names):
+    print("   %-22s %8d %8d" % (n, p[i] - p[0], p[i] - prev))
+    prev = p[i]
