@@ -27,6 +27,8 @@
 // net on s0 and target net on s1 in ONE launch).
 #pragma once
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #ifndef GEMM_BK
@@ -135,12 +137,21 @@ __device__ __forceinline__ int fdiv(int n, int /*d*/, unsigned m) {
 __device__ __forceinline__ int keep_if(int e, bool ok) { return e & -(int)ok; }
 
 struct ConvGeom { int H, W, C, KH, KW, S, OH, OW; unsigned m_run, m_ohw, m_ow; };
+// the launchers' guard for fdiv's validity range (largest index the loaders form x divisor < 2^32)
+inline void check_fastdiv(long n, long d, const char* what) {
+    if ((unsigned long long)n * (unsigned long long)d >= (1ull << 32)) {
+        fprintf(stderr, "pda: %s: index range %ld x divisor %ld exceeds the multiply-high division's bound (2^32)\n",
+                what, n, d);
+        abort();
+    }
+}
 inline ConvGeom make_geom(int H, int W, int C, int KH, int KW, int S) {
     ConvGeom g;
     g.H = H; g.W = W; g.C = C; g.KH = KH; g.KW = KW; g.S = S;
     g.OH = (H - KH) / S + 1;
     g.OW = (W - KW) / S + 1;
     g.m_run = fastdiv_magic(KW * C); g.m_ohw = fastdiv_magic(g.OH * g.OW); g.m_ow = fastdiv_magic(g.OW);
+    check_fastdiv((long)C * KH * KW + 4 * GEMM_BK, (long)KW * C, "conv geometry (reduction index)");
     return g;
 }
 

@@ -33,6 +33,7 @@ PDA_EXPORT void pda_conv_fwd_u8(const void* const* frames, const void* const* id
     }
     ConvGeom g = make_geom(H, W, C, KH, KW, S);
     int M = batch * g.OH * g.OW, K = C * KH * KW;
+    check_fastdiv((long)M + 4 * GEMM_BK, (long)g.OH * g.OW, "conv rows");
     GemmArgs<SrcFrameU8K, SrcDenseK, EpiBiasAct> a;
     for (int i = 0; i < ngroups; ++i) {
         a.g[i].a = {(const uint8_t*)frames[i], (const int*)idx[i], (long)C * H * W, g, M, K};
@@ -50,6 +51,7 @@ PDA_EXPORT void pda_conv_fwd(const void* const* x, const void* const* w, const v
                              int S, int O, int act, hipStream_t stream) {
     ConvGeom g = make_geom(H, W, C, KH, KW, S);
     int M = batch * g.OH * g.OW, K = C * KH * KW;
+    check_fastdiv((long)M + 4 * GEMM_BK, (long)g.OH * g.OW, "conv rows");
     GemmArgs<SrcIm2colK, SrcDenseK, EpiBiasAct> a;
     for (int i = 0; i < ngroups; ++i) {
         a.g[i].a = {(const bf16_t*)x[i], g, M, K};
@@ -144,6 +146,8 @@ PDA_EXPORT void pda_conv_dgrad(const void* dy, const void* w, const void* yin, v
         for (int px = 0; px < S; ++px) {
             DgradGeom g = make_dgrad_geom(cg, O, py, px);
             int M = batch * g.HC * g.WC;
+            check_fastdiv((long)M + 64, (long)g.HC * g.WC, "conv dgrad rows");
+            check_fastdiv((long)K + 4 * GEMM_BK, O, "conv dgrad reduction");
             a.g[ng].a = {(const bf16_t*)dy, g, M, K};
             a.g[ng].b = {(const bf16_t*)w, g, C, K};
             a.g[ng].e = {(bf16_t*)dx, (const bf16_t*)yin, yin ? act : ACT_NONE, g};
@@ -251,6 +255,7 @@ PDA_EXPORT void pda_conv_wgrad(const void* dy, const void* x, void* gw, void* gb
                                hipStream_t stream) {
     ConvGeom g = make_geom(H, W, C, KH, KW, S);
     int M = batch * g.OH * g.OW, K = C * KH * KW;
+    check_fastdiv((long)M + 4 * GEMM_BK, (long)g.OH * g.OW, "conv rows");
     GemmArgs<SrcDenseT, SrcIm2colT, EpiWgrad> a;
     a.g[0].a = {(const bf16_t*)dy, (long)O, O, M};
     a.g[0].b = {(const bf16_t*)x, g, K, M};
@@ -272,6 +277,7 @@ PDA_EXPORT void pda_conv_wgrad_pair(const void* const* dy, const void* const* x,
     for (int i = 0; i < 2; ++i) {
         ConvGeom g = make_geom(H[i], W[i], C[i], KH[i], KW[i], S[i]);
         int M = batch * g.OH * g.OW, K = C[i] * KH[i] * KW[i];
+        check_fastdiv((long)M + 4 * GEMM_BK, (long)g.OH * g.OW, "conv wgrad rows");
         a.g[i].a = {(const bf16_t*)dy[i], (long)O, O, M};
         a.g[i].b = {(const bf16_t*)x[i], g, K, M};
         a.g[i].e = {(float*)gw[i], (float*)gb[i], (long)K, slice_stride[i], bslice_stride[i], 1.f};
@@ -347,6 +353,7 @@ PDA_EXPORT void pda_conv_wgrad_u8(const void* dy, const void* frames, const void
                                   long slice_stride, long bslice_stride, int ksplit, hipStream_t stream) {
     ConvGeom g = make_geom(H, W, C, KH, KW, S);
     int M = batch * g.OH * g.OW, K = C * KH * KW;
+    check_fastdiv((long)M + 4 * GEMM_BK, (long)g.OH * g.OW, "conv rows");
     GemmArgs<SrcDenseT, SrcFrameU8T, EpiWgrad> a;
     a.g[0].a = {(const bf16_t*)dy, (long)O, O, M};
     a.g[0].b = {(const uint8_t*)frames, (const int*)idx, (long)C * H * W, g, K, M};

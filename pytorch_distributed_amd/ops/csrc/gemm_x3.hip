@@ -39,6 +39,7 @@ PDA_EXPORT void pda_x3_conv_fwd_u8(const void* const* frames, const void* const*
     }
     ConvGeom g = make_geom(H, W, C, KH, KW, S);
     int M = batch * g.OH * g.OW, K = C * KH * KW;
+    check_fastdiv((long)M + 4 * GEMM_BK, (long)g.OH * g.OW, "conv rows");
     GemmArgs<SPLIT_X2(SrcFrameU8K), SPLIT_HL2(SrcDenseK), EpiBiasAct> a;
     for (int i = 0; i < ngroups; ++i) {
         a.g[i].a = {{(const uint8_t*)frames[i], (const int*)idx[i], (long)C * H * W, g, M, K}, 0, K};
@@ -56,6 +57,7 @@ PDA_EXPORT void pda_x3_conv_fwd(const void* const* x, long x_plane, const void* 
                                 int H, int W, int C, int KH, int KW, int S, int O, int act, hipStream_t stream) {
     ConvGeom g = make_geom(H, W, C, KH, KW, S);
     int M = batch * g.OH * g.OW, K = C * KH * KW;
+    check_fastdiv((long)M + 4 * GEMM_BK, (long)g.OH * g.OW, "conv rows");
     GemmArgs<SPLIT_A3(SrcIm2colK), SPLIT_B3(SrcDenseK), EpiBiasAct> a;
     for (int i = 0; i < ngroups; ++i) {
         a.g[i].a = {{(const bf16_t*)x[i], g, M, K}, x_plane, K};
@@ -130,6 +132,8 @@ PDA_EXPORT void pda_x3_conv_dgrad(const void* dy, long dy_plane, const void* w, 
         for (int px = 0; px < S; ++px) {
             DgradGeom g = make_dgrad_geom(cg, O, py, px);
             int M = batch * g.HC * g.WC;
+            check_fastdiv((long)M + 64, (long)g.HC * g.WC, "conv dgrad rows");
+            check_fastdiv((long)K + 4 * GEMM_BK, O, "conv dgrad reduction");
             a.g[ng].a = {{(const bf16_t*)dy, g, M, K}, dy_plane, K};
             a.g[ng].b = {{(const bf16_t*)w, g, C, K}, w_plane, K};
             a.g[ng].e = {(bf16_t*)dx, (const bf16_t*)yin, yin ? act : ACT_NONE, g, dx_plane};
@@ -209,6 +213,7 @@ PDA_EXPORT void pda_x3_conv_wgrad(const void* const* dy, const long* dy_plane, c
     for (int i = 0; i < n; ++i) {
         ConvGeom g = make_geom(H[i], W[i], C[i], KH[i], KW[i], S[i]);
         int M = batch * g.OH * g.OW, K = C[i] * KH[i] * KW[i];
+        check_fastdiv((long)M + 4 * GEMM_BK, (long)g.OH * g.OW, "conv wgrad rows");
         a.g[i].a = {{(const bf16_t*)dy[i], (long)O, O, M}, dy_plane[i], M};
         a.g[i].b = {{(const bf16_t*)x[i], g, K, M}, x_plane[i], M};
         a.g[i].e = {(float*)gw[i], (float*)gb[i], (long)K, slice_stride[i], bslice_stride[i], 1.f};
@@ -230,6 +235,7 @@ PDA_EXPORT void pda_x3_conv_wgrad_u8(const void* dy, long dy_plane, const void* 
                                      hipStream_t stream) {
     ConvGeom g = make_geom(H, W, C, KH, KW, S);
     int M = batch * g.OH * g.OW, K = C * KH * KW;
+    check_fastdiv((long)M + 4 * GEMM_BK, (long)g.OH * g.OW, "conv rows");
     GemmArgs<SPLIT_HL2(SrcDenseT), SPLIT_X2(SrcFrameU8T), EpiWgrad> a;
     a.g[0].a = {{(const bf16_t*)dy, (long)O, O, M}, dy_plane, M};
     a.g[0].b = {{(const uint8_t*)frames, (const int*)idx, (long)C * H * W, g, K, M}, 0, M};
