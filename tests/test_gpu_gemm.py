@@ -52,6 +52,21 @@ def test_linear_fwd(nn, M, N, K):
     close(acc, x @ w.t(), 1e-3, 1e-3)
 
 
+@pytest.mark.parametrize("M,groups,ksplit", [(128, 2, 448), (640, 2, 3136), (200, 1, 1600)])
+def test_linear_fwd_slab_both_block_orders(nn, M, groups, ksplit):
+    """fc1's split-K forward as slabs: with >= 8 (slice, group) units the launch runs in XCD order, with fewer (large
+    batches: one slice) in plain block order -- the slices must add up to x w^T either way."""
+    torch.manual_seed(4)
+    N, K = 512, 3136
+    ns = nn.num_slices(K, ksplit)
+    xs = [bf(torch.randn(M, K, device="cuda")) for _ in range(groups)]
+    ws = [bf(torch.randn(N, K, device="cuda") / K ** 0.5) for _ in range(groups)]
+    outs = [torch.full((ns, M, N), 7.0, device="cuda") for _ in range(groups)]
+    nn.linear_fwd_slab([x.bfloat16() for x in xs], [w.bfloat16() for w in ws], outs, M, N, K, K, K, N, M * N, ksplit)
+    for x, w, o in zip(xs, ws, outs):
+        close(o.sum(0), x @ w.t(), 1e-3, 1e-3)
+
+
 def test_linear_fwd_grouped_tanh(nn):
     torch.manual_seed(1)
     M, N, K = 64, 96, 64
