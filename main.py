@@ -16,4 +16,5 @@ from pytorch_distributed_amd.utils.options import Options
 if __name__ == "__main__":
     mp.set_start_method("spawn", force=True)
     opt = Options(argv=[a for a in sys.argv[1:] if "=" in a])
-    run(opt)
+    sup = run(opt)
+    sys.exit(0 if getattr(sup, "ok", True) else 1)      # a job that lost a learner (or was stopped by one) is a failure

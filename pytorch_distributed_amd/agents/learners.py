@@ -9,8 +9,8 @@ What changed relative to the reference:
   `param_sync_freq` steps (utils/param_store.py);
 * prioritized replay is live: importance-weighted loss and |TD| write-back;
 * two step back-ends: "torch" (fp32 eager; CPU plumbing and the oracle) and
-  "native" (ops/dqn_engine.py, ops/ddpg_engine.py: HIP kernels, bf16 MFMA,
-  HBM replay, one captured graph per step) picked by `args.compute`.
+  "native" (ops/dqn_engine.py, ops/mlp_engine.py: HIP kernels, MFMA,
+  HBM replay, captured step graphs) picked by `args.compute`.
 
 `DqnTorchCore` / `DdpgTorchCore` hold the per-step arithmetic so tests and the
 benchmark can drive it without processes.
@@ -260,16 +260,42 @@ def load_learner_resume(args, core):
     return int(d["learner_step"]), int(d["actor_step"])
 
 
-def _host_inference(args, core, model, mailbox, device):
+def inference_slot_range(rank, world, num_slots):
+    """Mailbox slots [lo, hi) served by learner rank `rank` of `world`: contiguous, sizes differing by at most one.
+    Every rank hosts the native inference loop for ITS share of the env workers (reading its own live shadow
+    weights), so no rank carries the whole serving load and becomes the straggler of the synchronous step."""
+    base, rem = divmod(int(num_slots), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _host_inference(args, core, model, mailbox, device, slot_range=None):
     engine = getattr(core, "engine", None)
     if device.type != "cuda" or engine is None or not hasattr(engine, "online"):
         raise RuntimeError("inference_placement='learner' needs the native HIP learner core on a GPU")
     from ..ops.infer import make_native_server
-    server = make_native_server(args, model, mailbox, device, high_priority=True, weights=engine.online)
+    server = make_native_server(args, model, mailbox, device, high_priority=True, weights=engine.online,
+                                slot_range=slot_range)
     if server is None:
         raise RuntimeError("no native inference program for model_type %r" % args.model_type)
     server.start()
     return server
+
+
+def _maybe_peer_fault(args, core, rank, step):
+    """inject_fault="peer-withhold:R@S": from its S-th update on, learner rank R's peer all-reduce stops storing its
+    gradient slices into its peers (and every rank's waits give up after ~2 ms instead of a second), which is what a
+    dead xGMI link or a wedged peer looks like to them.  Test hook for the error-word check in the loop below."""
+    spec = getattr(args, "inject_fault", None)
+    if not spec or not spec.startswith("peer-withhold:"):
+        return
+    who, when = spec[len("peer-withhold:"):].split("@")
+    prog = getattr(core, "program", None)
+    if step != int(when) or prog is None or not getattr(prog, "peer", False):
+        return
+    for ar in (prog.ar_tail, prog.ar_head):
+        if hasattr(ar, "set_fault"):
+            ar.set_fault(withhold=(int(who) == rank), spin_limit=1 << 12)
 
 
 def _verify_learner_ranks(args, comm, rank, members):
@@ -323,7 +349,15 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
     rank = process_ind - args.num_actors - 1
     world = args.num_learners
     if args.device == "cuda":
-        ngpu = torch.cuda.device_count()
+        ngpu = torch.cuda.device_count()        # (does not initialise the GPU)
+        if world > 1 and getattr(args, "compute", "auto") != "torch" and "PDA_DP_GRAPH" not in os.environ:
+            # may the step graph contain the process group's collectives on this node?  Asked of a throw-away child
+            # BEFORE this process touches the GPU (parallel/preflight.py); only matters when the peer kernel is out
+            from ..parallel.preflight import choose_dp_graph_mode
+            os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                               "LOCAL_RANK": str((args.gpu_ind + rank) % max(ngpu, 1)),
+                               "MASTER_PORT": str(int(getattr(args, "dist_port", 29533)) + 101)})
+            os.environ["PDA_DP_GRAPH"] = choose_dp_graph_mode(port_offset=0)
         local_device = torch.device("cuda:%d" % ((args.gpu_ind + rank) % max(ngpu, 1)))
         torch.cuda.set_device(local_device)
     else:
@@ -335,7 +369,7 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
     from ..parallel.weight_sync import WeightPublisher, resolve_weight_sync
     collective_sync = resolve_weight_sync(args) == "collective"
     comm = make_comm(rank, world, local_device, port=getattr(args, "dist_port", None),
-                     extra_ranks=1 if collective_sync else 0)
+                     extra_ranks=1 if collective_sync else 0, backend=getattr(args, "dist_backend", None))
 
     if world > 1:       # (with collective weight sync the inference rank is the group's last member and joins in)
         _verify_learner_ranks(args, comm, rank, world + (1 if collective_sync else 0))
@@ -360,11 +394,17 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
 
     # batched actor inference hosted here: a native loop thread on a high-priority stream that
     # reads this learner's live bf16 shadow weights (no weight hand-off for the actors at all)
+    # With several learner ranks EVERY rank serves its share of the mailbox slots: rank 0 alone would run at a reduced
+    # rate and, the step being synchronous, hold all the others to it.
     hosted = None
-    if rank == 0 and args.actor_inference == "batched" and getattr(global_model, "mailbox", None) is not None:
+    if args.actor_inference == "batched" and getattr(global_model, "mailbox", None) is not None:
         from ..parallel.inference_server import resolve_placement
         if resolve_placement(args) == "learner":
-            hosted = _host_inference(args, core, local_model, global_model.mailbox, local_device)
+            lo, hi = inference_slot_range(rank, world, global_model.mailbox.num_slots)
+            if hi > lo:
+                hosted = _host_inference(args, core, local_model, global_model.mailbox, local_device,
+                                         slot_range=(lo, hi))
+                print("[learner %d] hosts batched inference for mailbox slots [%d, %d)" % (rank, lo, hi), flush=True)
 
     # weight hand-off (rank 0): seqlocked host buffer for evaluator / local actors (asynchronous D2H),
     # plus a collective broadcast to the inference rank when it owns another GPU
@@ -395,6 +435,7 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
     # its peers entered the next step's all-reduce would leave them blocked in it.  Every `agree_every` steps (and on
     # every pass while waiting for data) the ranks MIN-reduce "keep going"; in between nobody looks at the flag.
     agree_every = max(1, int(getattr(args, "stop_agree_every", 64)))
+    comm_errors, failed_comm = 0, False
     global_logs.beat("learner", process_ind)
     last_beat = time.time()
     from .actors import _maybe_fault
@@ -404,8 +445,25 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
             global_logs.beat("learner", process_ind)
             last_beat = now
         if world > 1:
-            if (not started or step % agree_every == 0) and not comm.all_agree(not global_logs.stop.value):
-                break
+            if not started or step % agree_every == 0:
+                # one MAX-reduce tells every rank the worst news: 0 carry on, 1 stop, 2 a peer all-reduce wait ran
+                # out on some rank (its error word; without this check the garbage sums would just feed Adam)
+                prog = getattr(core, "program", None)
+                err = prog.comm_error() if (started and hasattr(prog, "comm_error")) else 0
+                code = comm.agree_max(2 if err else (1 if global_logs.stop.value else 0))
+                if code == 2:
+                    comm_errors += 1
+                    policy = str(getattr(args, "dp_allreduce_on_error", "rccl"))
+                    print("[learner %d] peer all-reduce: a wait timed out (local error word 0x%x) at step %d -> %s"
+                          % (rank, err, step, "falling back to the process group's all-reduce" if policy == "rccl"
+                             else "stopping the job"), flush=True)
+                    if policy != "rccl":
+                        global_logs.stop.value = True
+                        failed_comm = True
+                        break
+                    prog.fall_back_to_collectives()
+                elif code:
+                    break
         elif global_logs.stop.value:
             break
         if hasattr(global_memory, "drain"):
@@ -414,7 +472,7 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
             ready = global_memory.size > ap.learn_start
             started = comm.all_agree(ready)
             if not started:
-                time.sleep(0.05 if hasattr(global_memory, "drain") else 1.0)
+                time.sleep(0.002 if hasattr(global_memory, "drain") else 1.0)
                 continue
         if max_ratio > 0:       # optional coupling of the learner to the data rate (absent in the reference)
             # (env steps taken before learning could start do not count: they would be paid back as one burst of
@@ -426,6 +484,7 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
         core.step()
         step += 1
         _maybe_fault(args, "learner", rank, step)
+        _maybe_peer_fault(args, core, rank, step)
         if rank == 0:
             with global_logs.learner_step.get_lock():
                 global_logs.learner_step.value += 1
@@ -457,9 +516,19 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
         print("[inference@learner] %d requests in %d batches (mean %.1f per batch, %.0f us per batch)"
               % (st["requests"], st["batches"], st["mean_batch"], st["mean_batch_us"]), flush=True)
         from ..parallel.inference_server import write_inference_stats
-        write_inference_stats(args, st, "learner")
+        write_inference_stats(args, st, "learner",
+                              "inference_stats.json" if rank == 0 else "inference_stats_rank%d.json" % rank)
         hosted.close()
+    if rank == 0 and world > 1:
+        import json
+        prog = getattr(core, "program", None)
+        with open(os.path.join(args.log_dir, "learner_comm.json"), "w") as f:
+            json.dump({"peer_allreduce_timeouts": comm_errors, "stopped_on_comm_error": failed_comm,
+                       "allreduce": getattr(prog, "allreduce_kind", getattr(comm, "backend", None)),
+                       "dp_graph": getattr(prog, "dp_graph_mode", None)}, f)
     comm.close()
+    if failed_comm:
+        raise SystemExit(3)     # a non-zero exit code: the supervisor reports the job as failed
 
 
 def dqn_learner(process_ind, args, global_logs, learner_logs, model_prototype,

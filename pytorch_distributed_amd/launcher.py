@@ -163,6 +163,9 @@ class Supervisor(object):
             if p.is_alive():
                 p.kill()
                 p.join(5)
+        for role, index, _, p in self.procs:       # a learner that left with an error after raising the stop flag itself
+            if role in self.FATAL_ROLES and p.exitcode not in (0, None) and self.failed is None:
+                self.failed = (role, index, p.exitcode)
         return [p.exitcode for _, _, _, p in self.procs]
 
     @property

@@ -120,6 +120,7 @@ class DeviceMemory(Memory):
         # learner thread only enqueues DMAs.  Host replay keeps the simple in-line pop.
         self.pump = None
         self._in_flight = []        # [(buffer index, event)] DMAs not yet known complete
+        self._copying = []          # [(slab, records)] chunks whose H2D copy was issued and whose unpack is still due
         if dev.type == "cuda" and getattr(self, "use_pump", True):
             import ctypes
             from ..parallel import hostlib
@@ -145,12 +146,16 @@ class DeviceMemory(Memory):
     def ingest_records(self, records_dev, n):
         """Scatter n packed records (already on the replay device) into the ring."""
         m = self.memory_size
-        base = self._pos_base[:n] if n <= self._pos_base.numel() else torch.arange(n, device=self.device)
-        positions = ((base + self.pos) % m).to(torch.int32)
         c = self.codec
-        replay_ops.unpack_records(records_dev, n, positions, self.state0s, self.state1s, self.tails,
-                                  c.state_bytes, c.state_stride, c.tail_floats)
-        if self.tree is not None:
+        if self.tree is None:
+            # uniform replay: the kernel derives every record's ring slot from (pos, m) itself -- no index tensor
+            replay_ops.unpack_records(records_dev, n, None, self.state0s, self.state1s, self.tails,
+                                      c.state_bytes, c.state_stride, c.tail_floats, pos_start=self.pos)
+        else:
+            base = self._pos_base[:n] if n <= self._pos_base.numel() else torch.arange(n, device=self.device)
+            positions = ((base + self.pos) % m).to(torch.int32)
+            replay_ops.unpack_records(records_dev, n, positions, self.state0s, self.state1s, self.tails,
+                                      c.state_bytes, c.state_stride, c.tail_floats)
             self.tree.update(positions, self._leaf_priority(self.init_priorities[positions.long()]))
         self.pos += n
         if self.pos >= m:
@@ -199,6 +204,18 @@ class DeviceMemory(Memory):
             self._slab_free.append(self._slab_busy.pop(0))
         moved = 0
         learner_stream = torch.cuda.current_stream(self.device)
+        # 1) chunks whose H2D copy HAS LANDED get their unpack kernel on the learner stream.  The learner stream never
+        #    waits for a DMA that is still in flight: a 14.5 MB chunk takes ~0.3 ms over PCIe, i.e. three whole learner
+        #    updates of stall per chunk when the unpack was ordered behind the copy it had just issued (round 2:
+        #    7.4 k updates/s inside the job against 10.4 k alone)
+        while self._copying and self._copy_evt[self._copying[0][0]].query():
+            d, n = self._copying.pop(0)
+            learner_stream.wait_event(self._copy_evt[d])    # complete already: an ordering edge, not a stall
+            self.ingest_records(self._slabs[d], n)
+            self._unpack_evt[d].record(learner_stream)
+            self._slab_busy.append(d)
+            moved += n
+        # 2) new chunks start their copies on the copy stream
         for _ in range(max_chunks):
             if not self._slab_free:
                 break               # every slab waits for the learner stream: back-pressure on the ring
@@ -211,11 +228,7 @@ class DeviceMemory(Memory):
                 self._slabs[d][:n].copy_(self.staging[i][:n], non_blocking=True)
                 self._copy_evt[d].record()
             self._in_flight.append((i, self._copy_evt[d]))
-            learner_stream.wait_event(self._copy_evt[d])
-            self.ingest_records(self._slabs[d], n)
-            self._unpack_evt[d].record(learner_stream)
-            self._slab_busy.append(d)
-            moved += n
+            self._copying.append((d, n))
         return moved
 
     def __del__(self):

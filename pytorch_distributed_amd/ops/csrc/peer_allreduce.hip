@@ -45,7 +45,9 @@ struct PeerRegionHeader {           // at the start of every rank's region
     unsigned epoch;                 // calls completed by this rank (+ the region's epoch base)
     unsigned done;                  // workgroups of the current call that have finished
     unsigned error;                 // != 0: a wait timed out (code = phase << 8 | awaited rank)
-    unsigned pad[13];
+    unsigned fault;                 // test hook: != 0 withholds this rank's phase-1 stores (its peers' waits run out)
+    unsigned spin_limit;            // polls before a wait gives up; 0 = PAR_SPIN_LIMIT (tests shorten it)
+    unsigned pad[11];
 };
 
 struct PeerArArgs {
@@ -142,6 +144,10 @@ __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs 
     const int r = a.rank, world = a.world;
     PeerRegionHeader* me = reinterpret_cast<PeerRegionHeader*>(a.region[r]);
     const unsigned epoch = ld_sys(&me->epoch) + 1u;         // every workgroup reads it before any can finish the call
+    // (both hooks live in device memory, not in the launch arguments: a captured launch replays them as they are NOW)
+    const bool withhold = ld_sys(&me->fault) != 0u;
+    const unsigned lim = ld_sys(&me->spin_limit);
+    const unsigned spin_limit = lim ? lim : PAR_SPIN_LIMIT;
     const long slice = a.slice, chunk = a.chunk;
     const long c0 = (long)j * chunk, c1 = min(c0 + chunk, slice);          // chunk range within a slice
     const unsigned slot = (unsigned)par_slot_bytes(slice, BF16);
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs 
     const __amdgpu_buffer_rsrc_t mine = rsrc_of(r);
 
     // ---- phase 1: my copy of peer p's slice -> p's staging slot r ----------------------------------------------
-    if (p != r) {
+    if (p != r && !withhold) {
         const __amdgpu_buffer_rsrc_t dst = rsrc_of(p);
         const unsigned base = hdr + (unsigned)r * slot;
         for (long e = c0 + (long)threadIdx.x * 4; e < c1; e += (long)PAR_THREADS * 4) {
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs 
                     }
                 if (all_ok) break;
                 __builtin_amdgcn_s_sleep(4);
-                if (++spins > PAR_SPIN_LIMIT) { atomicExch(&me->error, (1u << 8) | 0xffu); break; }
+                if (++spins > spin_limit) { atomicExch(&me->error, (1u << 8) | 0xffu); break; }
             }
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs 
                     if (!pair_ok(v[h], epoch)) { all_ok = false; v[h] = ld_pair(mine, goff + 16 * h); }
                 if (all_ok) break;
                 __builtin_amdgcn_s_sleep(4);
-                if (++spins > PAR_SPIN_LIMIT) { atomicExch(&me->error, (2u << 8) | (unsigned)p); break; }
+                if (++spins > spin_limit) { atomicExch(&me->error, (2u << 8) | (unsigned)p); break; }
             }
             float f[4];
             W::unpack(v, f);
@@ -255,10 +261,14 @@ __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs 
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 // geometry for n elements over `world` ranks: slice / chunk lengths and chunks per slice
-PDA_EXPORT void pda_peer_plan(long n, int world, long* slice, long* chunk, int* chunks) {
+// budget: workgroups of the launch as a whole (0 = 224, all resident on a GPU of its own; several ranks SHARING one
+// card -- rehearsals on a one-GPU box -- must fit all their launches on it together and ask for fewer).  Every rank
+// must use the same budget: the chunk geometry addresses the peers' regions.
+PDA_EXPORT void pda_peer_plan2(long n, int world, int budget, long* slice, long* chunk, int* chunks) {
     long sl = (n + world - 1) / world;
     sl = (sl + 7) / 8 * 8;
-    int target = 224 / world;                       // ~224 resident workgroups in all
+    if (budget <= 0) budget = 224;
+    int target = budget / world;                    // ~224 resident workgroups in all
     if (target > PAR_MAX_CHUNKS) target = PAR_MAX_CHUNKS;
     if (target < 1) target = 1;
     const long gran = 8L * world;                   // sub-chunks stay whole 16-byte accesses
@@ -267,6 +277,10 @@ PDA_EXPORT void pda_peer_plan(long n, int world, long* slice, long* chunk, int* 
     if (ch < gran) ch = gran;
     int nch = (int)((sl + ch - 1) / ch);
     *slice = sl; *chunk = ch; *chunks = nch;
+}
+
+PDA_EXPORT void pda_peer_plan(long n, int world, long* slice, long* chunk, int* chunks) {
+    pda_peer_plan2(n, world, 0, slice, chunk, chunks);
 }
 
 PDA_EXPORT long pda_peer_region_bytes(long n, int world, int wire_bf16) {
@@ -313,13 +327,25 @@ PDA_EXPORT int pda_peer_error(void* region) {
     return (int)v;
 }
 
+// clears the error word (after the caller has dealt with a timed-out wait); synchronises the device
+PDA_EXPORT int pda_peer_clear_error(void* region) {
+    return (int)hipMemset((char*)region + offsetof(PeerRegionHeader, error), 0, sizeof(unsigned));
+}
+
+// test hooks in the local region's header (synchronise the device): withhold this rank's phase-1 stores; polls before a
+// wait gives up (0 = default, about a second)
+PDA_EXPORT int pda_peer_set_fault(void* region, unsigned withhold, unsigned spin_limit) {
+    unsigned v[2] = {withhold, spin_limit};
+    return (int)hipMemcpy((char*)region + offsetof(PeerRegionHeader, fault), v, sizeof(v), hipMemcpyHostToDevice);
+}
+
 PDA_EXPORT int pda_peer_allreduce(void* const* regions, void* local, long n, int rank, int world, int wire_bf16,
-                                  hipStream_t stream) {
+                                  int budget, hipStream_t stream) {
     if (world < 2 || world > PAR_MAX_RANKS) return -1;
     PeerArArgs a;
     for (int i = 0; i < PAR_MAX_RANKS; ++i) a.region[i] = i < world ? (char*)regions[i] : nullptr;
     a.local = (float*)local; a.n = n; a.rank = rank; a.world = world;
-    pda_peer_plan(n, world, &a.slice, &a.chunk, &a.chunks);
+    pda_peer_plan2(n, world, budget, &a.slice, &a.chunk, &a.chunks);
     a.region_bytes = par_region_bytes(a.slice, world, wire_bf16 != 0);
     if (a.region_bytes >= (1L << 31)) return -2;            // buffer descriptors address 2 GB
     dim3 grid(world * a.chunks), block(PAR_THREADS);

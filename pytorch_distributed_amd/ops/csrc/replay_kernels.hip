@@ -127,14 +127,17 @@ PDA_EXPORT void pda_uniform_f32(void* out, int B, unsigned long long seed, void*
 
 // ---- replay: unpack packed transition records into the ring buffers -------------------------
 // One workgroup per record: 16-byte vector copies of both states, then the float tail.
+// pos == nullptr: record r goes to ring slot (pos_start + r) mod ring_size (uniform replay: no index tensor, no
+// launches to build one); otherwise to pos[r] (prioritized replay keeps the tensor for the tree update).
 __global__ __launch_bounds__(256) void replay_unpack_kernel(const uint8_t* __restrict__ rec, long rec_stride,
-                                                            const int* __restrict__ pos,
+                                                            const int* __restrict__ pos, long pos_start, long ring_size,
                                                             uint8_t* __restrict__ s0, uint8_t* __restrict__ s1,
                                                             int state_bytes, int state_stride,
                                                             float* __restrict__ tails, int tail_ld, int tail_floats) {
     int r = blockIdx.x;
     const uint8_t* src = rec + (long)r * rec_stride;
-    long dst_row = (long)pos[r] * state_bytes;
+    const long slot = pos ? (long)pos[r] : (pos_start + r) % ring_size;
+    long dst_row = slot * state_bytes;
     int vec = state_bytes / 16;
     const uint4* a = reinterpret_cast<const uint4*>(src);
     const uint4* b = reinterpret_cast<const uint4*>(src + state_stride);
@@ -149,14 +152,14 @@ __global__ __launch_bounds__(256) void replay_unpack_kernel(const uint8_t* __res
         }
     }
     const float* tl = reinterpret_cast<const float*>(src + 2 * (long)state_stride);
-    if (threadIdx.x < tail_floats) tails[(long)pos[r] * tail_ld + threadIdx.x] = tl[threadIdx.x];
+    if (threadIdx.x < tail_floats) tails[slot * tail_ld + threadIdx.x] = tl[threadIdx.x];
 }
-PDA_EXPORT void pda_replay_unpack(const void* rec, long rec_stride, int n, const void* pos, void* s0, void* s1,
-                                  int state_bytes, int state_stride, void* tails, int tail_ld, int tail_floats,
-                                  hipStream_t stream) {
+PDA_EXPORT void pda_replay_unpack(const void* rec, long rec_stride, int n, const void* pos, long pos_start,
+                                  long ring_size, void* s0, void* s1, int state_bytes, int state_stride, void* tails,
+                                  int tail_ld, int tail_floats, hipStream_t stream) {
     hipLaunchKernelGGL(replay_unpack_kernel, dim3(n), dim3(256), 0, stream, (const uint8_t*)rec, rec_stride,
-                       (const int*)pos, (uint8_t*)s0, (uint8_t*)s1, state_bytes, state_stride, (float*)tails,
-                       tail_ld, tail_floats);
+                       (const int*)pos, pos_start, ring_size > 0 ? ring_size : 1, (uint8_t*)s0, (uint8_t*)s1,
+                       state_bytes, state_stride, (float*)tails, tail_ld, tail_floats);
 }
 
 // ---- replay: gather B rows of row_bytes (multiple of 16) ------------------------------------------

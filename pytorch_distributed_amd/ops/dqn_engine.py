@@ -880,6 +880,46 @@ class DqnStepProgram(object):
     def _dp_whole(self):
         self._run_dp(self._part_a, self._part_b)
 
+    # ---- fail-safe: the peer kernel's waits are bounded; a wait that ran out leaves an error word ---------------------
+    def comm_error(self):
+        """0, or the error word of a peer all-reduce whose wait timed out on THIS rank (synchronises the device).
+        The learner loop MAX-reduces it over the ranks every `stop_agree_every` steps (agents/learners.py), so a
+        timed-out wait never feeds Adam for longer than that."""
+        if not self.dp:
+            return 0
+        err = 0
+        for ar in (self.ar_tail, self.ar_head):
+            if hasattr(ar, "error"):
+                err = max(err, abs(int(ar.error())))
+        return err
+
+    def fall_back_to_collectives(self):
+        """Collective: every rank leaves the peer kernel for the process group's all-reduce (RCCL / gloo).  The
+        updates since the failed wait used incomplete gradient sums, differently on each rank, so rank 0's
+        parameters, target network and optimizer state are re-broadcast before the step graphs are rebuilt."""
+        from ..parallel.peer_allreduce import _RcclAllReduce
+        e, comm = self.e, self.comm
+        torch.cuda.synchronize(e.device)
+        for name in ("ar_tail", "ar_head"):
+            ar = getattr(self, name)
+            if hasattr(ar, "clear_error"):
+                ar.clear_error()
+            ar.close()
+            setattr(self, name, _RcclAllReduce(comm))
+        self.allreduce_kind = self.ar_tail.kind
+        self.peer = False
+        self.grad_dtype = "fp32"
+        self.tail16 = None
+        step = e.adam.step_dev.to(torch.float32).reshape(-1)
+        for buf in (e.online.flat, e.target.flat, e.adam.m, e.adam.v, step):
+            comm.broadcast_(buf, src=0)
+        e.adam.step_dev.copy_(step.reshape(e.adam.step_dev.shape).to(e.adam.step_dev.dtype))
+        e.online.refresh()
+        e.target.refresh()
+        self.graphs, self.calls, self.ahead = None, 0, 0
+        self.presampled = False
+        torch.cuda.synchronize(e.device)
+
     def _capture_dp(self):
         """Preferred: the whole step, collectives included, as ONE graph (one host call per
         step: 4899 vs 3810 updates/s in the 1-rank RCCL rehearsal).  RCCL's intra-node
@@ -892,7 +932,9 @@ class DqnStepProgram(object):
         if self.peer and mode != "split":
             mode = "whole"      # the peer all-reduce is a plain kernel launch: nothing host-driven is left in the step
         if mode == "auto":
-            mode = "whole" if getattr(self.comm, "backend", None) == "nccl" else "split"
+            # RCCL inside a graph only when a pre-flight child has shown that this node captures and replays it
+            # (parallel/preflight.py sets PDA_DP_GRAPH=whole): a refused capture poisons the process
+            mode = "split"
         whole = self.comm.all_agree(mode == "whole")
         if whole:
             self.dp_graph_mode = "whole"

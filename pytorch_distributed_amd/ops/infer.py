@@ -64,8 +64,14 @@ def _L():
 
 
 class NativeInferenceServer(object):
-    def __init__(self, mailbox, device, seed=0, high_priority=False, window_us=0):
+    def __init__(self, mailbox, device, seed=0, high_priority=False, window_us=0, slot_range=None):
+        """slot_range (lo, hi): serve only these mailbox slots (several servers, e.g. one per learner rank, then
+        split the env workers between them); default all."""
         self.window_us = int(window_us)
+        lo, hi = slot_range if slot_range is not None else (0, mailbox.num_slots)
+        if not 0 <= lo < hi <= mailbox.num_slots:
+            raise ValueError("slot_range %r outside the mailbox's %d slots" % (slot_range, mailbox.num_slots))
+        self.slot_lo, self.slot_hi = int(lo), int(hi)
         self.mailbox = mailbox
         self.device = torch.device(device)
         self.seed = int(seed)
@@ -80,13 +86,14 @@ class NativeInferenceServer(object):
         mb = self.mailbox
         cfg = _InferConfig()
         cfg.kind = kind
-        cfg.nslots = mb.num_slots
-        cfg.seq = mb.seq.data_ptr()
-        cfg.obs = mb.obs.data_ptr()
+        lo = self.slot_lo           # the server sees slots [lo, hi) as its slots 0 .. hi - lo - 1
+        cfg.nslots = self.slot_hi - lo
+        cfg.seq = mb.seq.data_ptr() + lo * mb.seq.stride(0) * mb.seq.element_size()
         cfg.obs_stride = mb.obs[0].numel() * mb.obs.element_size()
-        cfg.out = mb.out.data_ptr()
+        cfg.obs = mb.obs.data_ptr() + lo * cfg.obs_stride
         cfg.out_ld = mb.out.shape[1]
-        cfg.eps = mb.eps.data_ptr()
+        cfg.out = mb.out.data_ptr() + lo * cfg.out_ld * mb.out.element_size()
+        cfg.eps = mb.eps.data_ptr() + lo * mb.eps.element_size()
         cfg.seed = (self.seed * 2654435761 + 97) & 0xFFFFFFFFFFFF
         cfg.high_priority = 1 if self.high_priority else 0
         cfg.max_bucket = 0
@@ -181,7 +188,7 @@ class NativeInferenceServer(object):
             self.handle = None
 
 
-def make_native_server(args, model, mailbox, device, high_priority=False, weights=None):
+def make_native_server(args, model, mailbox, device, high_priority=False, weights=None, slot_range=None):
     """Server for the configured model family, or None when the family has no native program
     (the caller then serves from Python)."""
     window_us = int(getattr(args, "inference_window_us", 0))
@@ -190,11 +197,12 @@ def make_native_server(args, model, mailbox, device, high_priority=False, weight
         geom = CnnGeometry(model.input_dims, model.output_dims, model.critic[1][0].out_features)
         w = weights if weights is not None else CnnWeights(model, geom, with_grad=False)
         return NativeInferenceServer(mailbox, device, seed=args.seed + 4242, high_priority=high_priority,
-                                     window_us=window_us).build_cnn(w, geom, model.norm_val, model)
+                                     window_us=window_us, slot_range=slot_range).build_cnn(w, geom, model.norm_val,
+                                                                                           model)
     if args.model_type == "ddpg-mlp":
         from .mlp_engine import DDPG_LAYERS, MlpWeights
         w = weights if weights is not None else MlpWeights(model, DDPG_LAYERS, with_grad=False,
                                                            fp32_only=("critic.1.2",))
         return NativeInferenceServer(mailbox, device, seed=args.seed + 4242, high_priority=high_priority,
-                                     window_us=window_us).build_ddpg_actor(w, model)
+                                     window_us=window_us, slot_range=slot_range).build_ddpg_actor(w, model)
     return None

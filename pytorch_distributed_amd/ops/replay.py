@@ -20,21 +20,27 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def unpack_records(records, n, positions, state0s, state1s, tails, state_bytes, state_stride, tail_floats):
+def unpack_records(records, n, positions, state0s, state1s, tails, state_bytes, state_stride, tail_floats,
+                   pos_start=0):
     """records (>=n, record_bytes) uint8 on the replay device; positions (n,)
-    int32 ring slots.  Writes state0s[pos], state1s[pos] (raw bytes) and
-    tails[pos, :tail_floats]."""
+    int32 ring slots, or None: record r goes to slot (pos_start + r) mod len(state0s), computed
+    inside the kernel.  Writes state0s[pos], state1s[pos] (raw bytes) and tails[pos, :tail_floats]."""
     if n == 0:
         return
     dev = state0s.device
+    m = int(state0s.shape[0])
     if dev.type == "cuda":
         if not native_available():
             from . import native_error
             raise RuntimeError("unpack_records on a GPU needs the HIP library: " + native_error())
-        lib().pda_replay_unpack(_p(records), int(records.stride(0)), int(n), _p(positions),
+        lib().pda_replay_unpack(_p(records), ctypes.c_long(int(records.stride(0))), int(n),
+                                _p(positions) if positions is not None else ctypes.c_void_p(0),
+                                ctypes.c_long(int(pos_start)), ctypes.c_long(m),
                                 _p(state0s), _p(state1s), int(state_bytes), int(state_stride),
                                 _p(tails), int(tails.stride(0)), int(tail_floats), _stream(dev))
         return
+    if positions is None:
+        positions = (torch.arange(n, device=dev) + int(pos_start)) % m
     pos = positions[:n].long()
     rec = records[:n]
     s0 = rec[:, :state_bytes]

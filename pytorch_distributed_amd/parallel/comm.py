@@ -43,6 +43,10 @@ class SingleComm(object):
     def all_agree(self, flag):
         return bool(flag)
 
+    def agree_max(self, code):
+        """MAX over ranks of a small non-negative status code (0 = carry on): every rank learns the worst news."""
+        return int(code)
+
     def barrier(self):
         pass
 
@@ -138,6 +142,11 @@ class TorchComm(SingleComm):
         self._all_reduce(self._flag, dist.ReduceOp.MIN)
         return bool(self._flag.item())
 
+    def agree_max(self, code):
+        self._flag.fill_(int(code))
+        self._all_reduce(self._flag, dist.ReduceOp.MAX)
+        return int(self._flag.item())
+
     def verify_ranks(self):
         """Proof that `world_size` DISTINCT ranks take part in this group's collectives: MIN / MAX / SUM
         all-reduces of the rank id, and an all-gather of (rank, device index, device uuid hash).
@@ -225,6 +234,9 @@ class FakeComm(SingleComm):
                 t.copy_(ts[src])
         self._collect("bc", flat, fn)     # ranks must call in rank order
         return flat
+
+    def agree_max(self, code):
+        return int(code)        # (logical ranks of one process: nothing to disagree about)
 
 
 def make_comm(rank, world_size, device, port=None, backend=None, extra_ranks=0):

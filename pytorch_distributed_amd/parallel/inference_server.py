@@ -171,7 +171,7 @@ class BatchedPolicy(object):
         return act.float().cpu().numpy(), z, z
 
 
-def write_inference_stats(args, st, where):
+def write_inference_stats(args, st, where, name="inference_stats.json"):
     """Leave the serving counters where the parent (bench.py --node, bench/node_throughput.py) can read them."""
     import json
     import os
@@ -181,19 +181,36 @@ def write_inference_stats(args, st, where):
                                    "live_slots", "registered") if k in st}
         keep["where"] = where
         keep["window_us"] = int(getattr(args, "inference_window_us", 0))
-        with open(os.path.join(args.log_dir, "inference_stats.json"), "w") as f:
+        with open(os.path.join(args.log_dir, name), "w") as f:
             json.dump(keep, f)
     except OSError:
         pass
 
 
 def resolve_placement(args):
-    """Where the batched policy runs: "learner" = a native loop thread inside learner rank 0 (shares
-    the learner's live weights, high-priority stream), "process" = a process of its own."""
+    """Where the batched policy runs: "learner" = a native loop thread inside EVERY learner rank, each serving its
+    share of the mailbox slots from the rank's live weights on a high-priority stream (agents/learners.py);
+    "process" = a process of its own.  auto: "learner" whenever the learners run the native core."""
     place = getattr(args, "inference_placement", "auto")
     if place != "auto":
         return place
-    return "process"
+    return "learner" if native_learner_expected(args) else "process"
+
+
+def native_learner_expected(args):
+    """True when the learner processes of this job will run a native (HIP) core with live shadow weights that a
+    hosted inference loop can read: GPU device, compute not forced to torch, the library built, a model family
+    with a native serving program.  Decided from the options alone (the launcher's parent never touches the GPU),
+    so the launcher and every learner rank reach the same answer."""
+    import os
+    if getattr(args, "device", "cpu") != "cuda" or getattr(args, "compute", "auto") == "torch":
+        return False
+    if args.model_type not in ("dqn-cnn", "ddpg-mlp"):
+        return False
+    if str(getattr(args, "weight_sync", "auto")) == "collective":
+        return False            # an explicit request for the broadcast path implies a serving process of its own
+    from .. import ops
+    return os.path.exists(ops.LIB_PATH)
 
 
 def _native_server(args, model, mailbox, device):
@@ -223,7 +240,7 @@ def inference_server(process_ind, args, global_logs, model_prototype, global_mod
         # join the learners' process group as rank L; weights then arrive by broadcast from rank 0
         from .comm import make_comm
         comm = make_comm(args.num_learners, args.num_learners, device, port=getattr(args, "dist_port", None),
-                         extra_ranks=1)
+                         extra_ranks=1, backend=getattr(args, "dist_backend", None))
         if args.num_learners > 1:
             comm.verify_ranks()     # the learners' membership check is a collective of the whole group (agents/learners.py)
         receiver = WeightReceiver(comm, model.flatten_(with_grad=False).numel(), device)

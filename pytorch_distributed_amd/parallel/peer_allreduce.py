@@ -38,6 +38,9 @@ def _lib():
         L.pda_peer_plan.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.POINTER(ctypes.c_long),
                                     ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_int)]
         L.pda_peer_plan.restype = None
+        L.pda_peer_plan2.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_long),
+                                     ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_int)]
+        L.pda_peer_plan2.restype = None
         L.pda_peer_region_bytes.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int]
         L.pda_peer_region_bytes.restype = ctypes.c_long
         L.pda_peer_alloc.argtypes = [ctypes.c_long, ctypes.c_uint, ctypes.POINTER(_vp), ctypes.c_char_p]
@@ -50,19 +53,30 @@ def _lib():
         L.pda_peer_free.restype = ctypes.c_int
         L.pda_peer_error.argtypes = [_vp]
         L.pda_peer_error.restype = ctypes.c_int
+        L.pda_peer_clear_error.argtypes = [_vp]
+        L.pda_peer_clear_error.restype = ctypes.c_int
+        L.pda_peer_set_fault.argtypes = [_vp, ctypes.c_uint, ctypes.c_uint]
+        L.pda_peer_set_fault.restype = ctypes.c_int
         L.pda_peer_allreduce.argtypes = [ctypes.POINTER(_vp), _vp, ctypes.c_long, ctypes.c_int, ctypes.c_int,
-                                         ctypes.c_int, _vp]
+                                         ctypes.c_int, ctypes.c_int, _vp]
         L.pda_peer_allreduce.restype = ctypes.c_int
         L._peer_ready = True
     return L
 
 
-def plan(numel, world):
+def plan(numel, world, budget=0):
     """(slice, chunk, chunks per slice) the kernel uses for `numel` elements over `world` ranks."""
     L = _lib()
     sl, ch, n = ctypes.c_long(), ctypes.c_long(), ctypes.c_int()
-    L.pda_peer_plan(int(numel), int(world), ctypes.byref(sl), ctypes.byref(ch), ctypes.byref(n))
+    L.pda_peer_plan2(int(numel), int(world), int(budget), ctypes.byref(sl), ctypes.byref(ch), ctypes.byref(n))
     return sl.value, ch.value, n.value
+
+
+def workgroup_budget():
+    """Workgroups per all-reduce launch (0 = the kernel's 224, sized for one rank per GPU).  Ranks that SHARE a card
+    (one-GPU rehearsals: PDA_PEER_WORKGROUPS, set for all ranks alike by whoever starts them) need all their launches
+    resident on it together, or their waits for each other run out."""
+    return int(os.environ.get("PDA_PEER_WORKGROUPS", "0") or 0)
 
 
 _regions_created = 0        # per process; every rank creates its regions in the same (collective) order
@@ -80,6 +94,7 @@ class PeerAllReduce(object):
         if wire not in ("fp32", "bf16"):
             raise ValueError("wire must be 'fp32' or 'bf16'")
         self.wire_bf16 = 1 if wire == "bf16" else 0
+        self.budget = workgroup_budget()
         self.local, self.peers, self.closed = None, {}, False
         L = _lib()
         torch.cuda.set_device(self.device)
@@ -90,13 +105,15 @@ class PeerAllReduce(object):
         self.epoch_base = (_regions_created << 22) & 0x7FFFFFFF       # 4 M calls per region before bases could meet
         rc = L.pda_peer_alloc(nbytes, self.epoch_base, ctypes.byref(ptr), handle)
         mine = {"rank": self.rank, "rc": int(rc), "handle": handle.raw if rc == 0 else b"", "pid": os.getpid(),
-                "bytes": int(nbytes), "epoch_base": self.epoch_base}
+                "bytes": int(nbytes), "epoch_base": self.epoch_base, "budget": self.budget}
         if rc == 0:
             self.local = ptr.value
         everyone = [None] * self.world
         dist.all_gather_object(everyone, mine, group=getattr(comm, "group", None))
         err = None
-        if len({e["epoch_base"] for e in everyone}) != 1:
+        if len({e["budget"] for e in everyone}) != 1:
+            err = "ranks disagree on the workgroup budget (PDA_PEER_WORKGROUPS must be the same everywhere)"
+        elif len({e["epoch_base"] for e in everyone}) != 1:
             err = "ranks disagree on the region's epoch base (regions must be created in the same order everywhere)"
         elif any(e["rc"] != 0 for e in everyone):
             err = "hipExtMallocWithFlags / hipIpcGetMemHandle failed on ranks %s" % [e["rank"] for e in everyone if e["rc"]]
@@ -128,7 +145,7 @@ class PeerAllReduce(object):
         assert flat.dtype == torch.float32 and flat.is_contiguous() and flat.numel() == self.numel
         assert flat.data_ptr() % 16 == 0, "gradient bucket must start on a 16-byte boundary"
         rc = _lib().pda_peer_allreduce(self.regions, _vp(flat.data_ptr()), self.numel, self.rank, self.world,
-                                       self.wire_bf16, _vp(torch.cuda.current_stream().cuda_stream))
+                                       self.wire_bf16, self.budget, _vp(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise RuntimeError("peer all-reduce launch failed: hipError %d" % rc)
         return flat
@@ -136,6 +153,18 @@ class PeerAllReduce(object):
     def error(self):
         """0, or the code of the wait that timed out ((phase << 8) | awaited rank).  Synchronises the device."""
         return int(_lib().pda_peer_error(_vp(self.local))) if self.local else -1
+
+    def set_fault(self, withhold=False, spin_limit=0):
+        """Test hooks, kept in the region's header so that they also reach launches replayed from a graph:
+        withhold this rank's stores (its peers' bounded waits then run out and raise THEIR error words); polls
+        before a wait gives up (0 = the kernel's default, about a second)."""
+        if self.local:
+            torch.cuda.synchronize(self.device)
+            _lib().pda_peer_set_fault(_vp(self.local), 1 if withhold else 0, int(spin_limit))
+
+    def clear_error(self):
+        if self.local:
+            _lib().pda_peer_clear_error(_vp(self.local))
 
     def close(self):
         if self.closed:
@@ -168,6 +197,9 @@ class _RcclAllReduce(object):
 
     def all_reduce_sum_(self, flat):
         return self.comm.all_reduce_sum_(flat)
+
+    def error(self):
+        return 0
 
     def close(self):
         pass
@@ -284,7 +316,7 @@ def _worker():
         graphed = bool(torch.equal(y, got))
         case = {"numel": numel, "wire": wire, "max_err_vs_group_sum": err, "tol": tol, "same_bits_on_all_ranks": same,
                 "chained_calls_ok": chained, "graph_replay_ok": graphed, "us_per_call_in_graph": round(1e6 * dt, 1),
-                "kernel_error_word": peer.error(), "plan": plan(numel, world)}
+                "kernel_error_word": peer.error(), "plan": plan(numel, world, peer.budget)}
         if err > tol:       # where, and what the two sums and this rank's own contribution are there
             bad = ((got - ref).abs() > tol).nonzero().reshape(-1)
             case["bad_count"] = int(bad.numel())

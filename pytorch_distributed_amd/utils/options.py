@@ -142,7 +142,8 @@ class Params(object):
         # --- MI355X-native extensions -------------------------------------
         self.device = _default_device()     # learner / inference device: "cuda" | "cpu"
         self.actor_inference = "local"      # "local": per-actor model copy | "batched": GPU inference server
-        self.inference_placement = "auto"   # batched inference runs in a "process" of its own | inside the "learner"
+        self.inference_placement = "auto"   # batched inference runs in a "process" of its own | inside the "learner" ranks
+                                            # (each rank serves 1/N of the env workers); auto: learner with the native core
         self.inference_window_us = 40       # native batched inference: a partial batch waits this long for the other live
                                             # envs' requests (0: answer at once); measured in profiles/r2_node_*.json
         self.resume = False                 # continue from ./models/MACHINE_TIMESTAMP.resume.pth (optimizer, target, counters)
@@ -166,7 +167,12 @@ class Params(object):
         self.watchdog_actor_s = 120.0       # a silent actor is terminated and restarted (0: no watchdog)
         self.shutdown_grace_s = 20.0        # time the remaining processes get once the job is over, before terminate()
         self.stop_agree_every = 64          # several learner ranks: they agree on leaving the loop every this many steps
+                                            # (the same reduce carries the peer all-reduce's error word)
+        self.dp_allreduce_on_error = "rccl" # a peer all-reduce wait timed out on some rank: "rccl" = every rank switches to
+                                            # the process group's all-reduce and re-syncs from rank 0 | "stop" = the job
+                                            # ends with a non-zero exit code.  It never silently continues.
         self.ingest = "ring"                # "ring": lock-free shm ring into device replay | "direct"
+        self.dist_backend = None            # process-group back-end of the learner ranks (None: "nccl" = RCCL on GPUs, gloo on CPU)
         self.allow_shared_gpu = False       # num_learners > visible GPUs: refuse (False) or let ranks share a card (rehearsal)
         self.force_dp = False               # run the data-parallel step program even with one learner (rehearsal)
         self.graph_steps = 5                # native DQN learner, HBM replay, one rank: updates per hipGraph replay (the

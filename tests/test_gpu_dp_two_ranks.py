@@ -62,3 +62,25 @@ def test_two_rank_dp_with_the_peer_allreduce_in_one_graph(precision):
     assert res["ranks_distinct"] is True
     assert res["final_loss"] == res["final_loss"] and res["value"] > 0
     print(json.dumps({k: res[k] for k in ("value", "ms_per_step", "dp_allreduce", "dp_graph")}))
+
+
+@pytest.mark.gpu
+def test_eight_rank_dp_step_on_one_card():
+    """The node size the data-parallel step is built for: eight ranks (here eight processes on one card), the peer
+    all-reduce inside the captured step, every rank bit-identical afterwards."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PDA_DP_GRAPH", "PDA_DP_ALLREDUCE"):
+        env.pop(k, None)
+    env["PDA_BENCH_FAULTHANDLER"] = "110"
+    env["PDA_PEER_WORKGROUPS"] = "64"       # eight ranks' all-reduce launches resident on the one card together
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5",
+           "--backend", "gloo", "--share-gpu", "--replay", "2048", "--min-time", "0", "--precision", "bf16",
+           "--allreduce", "peer", "--launch-timeout", "110"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=118)
+    assert out.returncode == 0, out.stderr.decode(errors="replace")[-2000:]
+    res = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 8 and res["config"]["global_batch"] == 8 * 128
+    assert res["dp_allreduce"] == "peer-fp32" and res["dp_graph"] == "whole"
+    assert res["dp_param_max_abs_diff_across_ranks"] == 0.0 and res["dp_allreduce_errors"] == 0
+    assert res["rccl_ranks"] == 8 and res["ranks_distinct"] is True and res["rank_id_min_max_sum"] == [0, 7, 28]
+    assert res["final_loss"] == res["final_loss"] and res["value"] > 0

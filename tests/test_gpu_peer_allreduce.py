@@ -5,6 +5,8 @@ the one-GPU rehearsal cannot show is the link bandwidth.  Checked per rank: the 
 wire -- the rank-ordered sum of all ranks' vectors gathered on the host, every rank holds the same bits, back-to-back calls and hipGraph replays keep working (the epoch is
 handed over in device memory), and no wait timed out.
 
+world = 8 is PAR_MAX_RANKS, the node size the kernel is built for (8 x 224 workgroups resident on one card here).
+
 Replaces the reference's abandoned gradient hand-off (/root/reference/utils/helpers.py:28-34)."""
 import json
 import os
@@ -28,6 +30,8 @@ def _launch(world, timeout=110):
         env = dict(os.environ)
         env.update(RANK=str(r), WORLD_SIZE=str(world), MASTER_PORT=str(port), PDA_PEER_SHARE_GPU="1",
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if world > 4:       # all ranks' launches must be resident on the ONE card together (8 x 224 workgroups are not)
+            env["PDA_PEER_WORKGROUPS"] = "64"
         procs.append(subprocess.Popen([sys.executable, "-m", "pytorch_distributed_amd.parallel.peer_allreduce"],
                                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
     outs = []
@@ -42,7 +46,7 @@ def _launch(world, timeout=110):
     return outs
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_peer_allreduce_across_processes(world):
     outs = _launch(world)
     for rc, out, err in outs:
