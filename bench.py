@@ -76,7 +76,9 @@ def parse_args(argv=None):
                          "learner + evaluator, bench/node_throughput.py) for a bounded number of learner steps and "
                          "report env frames/s + learner updates/s measured inside it under \"node\" "
                          "(auto: on a GPU with --gpus 1)")
-    ap.add_argument("--node-steps", type=int, default=40000, help="learner steps of the --node job")
+    ap.add_argument("--node-steps", type=int, default=200000,
+                    help="learner steps of the --node job (200 k = >= 20 s of steady learning = >= 10 logger windows of "
+                         "2 s, whose mean / std / min / max are reported)")
     ap.add_argument("--node-actors", type=int, default=8)
     ap.add_argument("--node-envs-per-actor", type=int, default=2)
     ap.add_argument("--node-timeout", type=float, default=240.0)
@@ -174,8 +176,10 @@ def run_node_job(a, precision, device):
            "--envs-per-actor", str(a.node_envs_per_actor), "--precision", precision,
            "--device", "cuda" if str(device).startswith("cuda") else "cpu"]
     try:
+        env = dict(os.environ)
+        env["PDA_LEARNER_PROF"] = "1"       # where the in-job learner's time goes (agents/learners.py _LoopProfile)
         p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT,
-                             start_new_session=True)
+                             start_new_session=True, env=env)
         try:
             stdout, _ = p.communicate(timeout=a.node_timeout)
         except subprocess.TimeoutExpired:
@@ -187,7 +191,9 @@ def run_node_job(a, precision, device):
                 d = json.loads(line)
                 keep = ("num_actors", "num_envs_per_actor", "actor_inference", "precision", "learner_steps", "wall_s",
                         "learner_updates_per_sec_steady", "env_frames_per_sec_mean", "env_frames_per_sec_peak",
-                        "actor_steps_per_sec_mean", "inference", "exitcodes", "actor_restarts", "env", "memory")
+                        "actor_steps_per_sec_mean", "inference", "exitcodes", "actor_restarts", "env", "memory",
+                        "learner_updates_per_sec_windows", "env_frames_per_sec_windows", "logger_window_s",
+                        "learner_loop_profile")
                 d = {k: d.get(k) for k in keep}
                 d["env_frames_per_sec"] = d.pop("env_frames_per_sec_mean")
                 d["learner_updates_per_sec_in_job"] = d.pop("learner_updates_per_sec_steady")

@@ -90,6 +90,24 @@ def main():
         busy = busy[:-1]
     frame_mult = 4 if opt.env_type in ("atari", "synthetic") else 1
     steps_per_s = [v for _, _, v in fps if v > 0]
+    # the same steady windows for the actors (the learner's windows are the logger's windows)
+    steady_fps = [frame_mult * v for (_, s, v), (_, s_prev, _) in zip(fps[1:], fps[:-1]) if s_prev > 0 and v > 0]
+    if len(steady_fps) > 1:
+        steady_fps = steady_fps[:-1]
+
+    def spread(xs):
+        if not xs:
+            return None
+        m = sum(xs) / len(xs)
+        sd = (sum((x - m) ** 2 for x in xs) / max(len(xs) - 1, 1)) ** 0.5
+        return {"windows": len(xs), "mean": round(m, 1), "std": round(sd, 1), "min": round(min(xs), 1),
+                "max": round(max(xs), 1)}
+    loop_profile = None
+    try:
+        with open(os.path.join(opt.log_dir, "learner_loop_profile.json")) as f:
+            loop_profile = json.load(f)
+    except (OSError, ValueError):
+        pass
     infer = None
     try:
         with open(os.path.join(opt.log_dir, "inference_stats.json")) as f:
@@ -104,6 +122,8 @@ def main():
         "compute": opt.compute, "precision": opt.precision, "inference": infer, "batch_size": opt.agent_params.batch_size, "nstep": opt.agent_params.nstep,
         "learner_steps": a.steps, "wall_s": round(wall, 1),
         "learner_updates_per_sec_steady": round(sum(busy) / len(busy), 1) if busy else None,
+        "learner_updates_per_sec_windows": spread(busy), "env_frames_per_sec_windows": spread(steady_fps),
+        "logger_window_s": opt.agent_params.logger_freq, "learner_loop_profile": loop_profile,
         "learner_updates_per_sec_peak": round(max([v for _, _, v in ups] or [0]), 1),
         "actor_steps_per_sec_mean": round(sum(steps_per_s) / len(steps_per_s), 1) if steps_per_s else None,
         "env_frames_per_sec_mean": round(frame_mult * sum(steps_per_s) / len(steps_per_s), 1) if steps_per_s else None,

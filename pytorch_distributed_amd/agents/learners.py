@@ -76,7 +76,7 @@ class _TorchCore(object):
     def flat_params(self):
         return self.model.flat_params
 
-    def loss_values(self):
+    def loss_values(self, lagged=False):
         return {k: float(v) for k, v in self.last_losses.items()}
 
     # ---- true resume (the reference can only warm-start from the plain state_dict) ----------
@@ -282,6 +282,113 @@ def _host_inference(args, core, model, mailbox, device, slot_range=None):
     return server
 
 
+class _LoopProfile(object):
+    """PDA_LEARNER_PROF=1: where the learner loop's wall time goes inside the whole job -- host time in drain() /
+    core.step() / the rest of an iteration, and how often the GPU had ALREADY run dry when the next step was handed
+    to it (host-bound) -- written to <log_dir>/learner_loop_profile.json at the end.  Off by default: the stream
+    query costs a few microseconds per iteration."""
+
+    def __init__(self, device):
+        self.device = device
+        self.t = {"drain": 0.0, "step": 0.0, "rest": 0.0}
+        self.iters = 0
+        self.starved = 0
+        self.t0 = None
+        self.mark = None
+        self.pairs, self.replays, self.syncs = [], 0, 0
+
+    def begin(self):
+        now = time.perf_counter()
+        if self.mark is not None:
+            self.t["rest"] += now - self.mark
+        if self.t0 is None:
+            self.t0 = now
+        self.mark = now
+
+    def lap(self, name):
+        now = time.perf_counter()
+        self.t[name] += now - self.mark
+        self.mark = now
+
+    def before_step(self, core=None):
+        self.iters += 1
+        if self.device.type != "cuda":
+            return
+        self.queries = getattr(self, "queries", 0)
+        if self.iters % 16 == 0:    # (sampled: the query costs a few microseconds)
+            self.queries += 1
+            if torch.cuda.current_stream(self.device).query():
+                self.starved += 1   # everything queued so far has finished: the GPU is waiting for the host
+        # GPU-side timing of the step graphs themselves: bursts of 8 consecutive replays, an event in front of and
+        # behind each (replay time, and the stream time BETWEEN two replays: unpack kernels, size updates, idling)
+        prog = getattr(core, "program", None)
+        self._pending_evt = None
+        if prog is not None and getattr(prog, "ahead", 0) == 0 and len(self.pairs) < 4000:
+            self.replays += 1
+            if 200 <= self.replays < 3200:  # a continuous stretch: every replay and every gap of ~1.8 s of learning
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                chunks = int(getattr(getattr(core, "memory", None), "chunks_unpacked", 0))
+                self._pending_evt = (e0, e1, self.replays, int(getattr(prog, "graph_steps", 1)), chunks, self.syncs)
+
+    def after_step(self):
+        if getattr(self, "_pending_evt", None) is not None:
+            self._pending_evt[1].record()
+            self.pairs.append(self._pending_evt)
+            self._pending_evt = None
+
+    def dump(self, args, rank, steps):
+        import json
+        wall = time.perf_counter() - (self.t0 or time.perf_counter())
+        out = {"rank": rank, "steps": steps, "iterations": self.iters, "wall_s": round(wall, 3),
+               "host_seconds": {k: round(v, 3) for k, v in self.t.items()},
+               "host_us_per_iteration": {k: round(1e6 * v / max(self.iters, 1), 2) for k, v in self.t.items()},
+               "gpu_idle_at_submit_fraction": round(self.starved / max(getattr(self, "queries", 0), 1), 4)}
+        if self.pairs:
+            torch.cuda.synchronize(self.device)
+            rep = [1e3 * p[0].elapsed_time(p[1]) / p[3] for p in self.pairs[8:]]
+            # the same gaps by what the host put between the two replays: nothing / unpack kernel(s) of ingested
+            # chunks / a host synchronisation (loss read-out), after which the GPU waits for the host to catch up
+            kinds = {"plain": [], "with_unpack": [], "after_host_sync": []}
+            for p, q in zip(self.pairs[8:-1], self.pairs[9:]):
+                if q[2] != p[2] + 1:
+                    continue
+                g = 1e3 * p[1].elapsed_time(q[0])
+                kinds["after_host_sync" if q[5] != p[5] else ("with_unpack" if q[4] != p[4] else "plain")].append(g)
+            out["gpu_us_between_replays_by_kind"] = {
+                k: {"n": len(v), "mean": round(sum(v) / len(v), 2), "median": round(sorted(v)[len(v) // 2], 2)}
+                for k, v in kinds.items() if v}
+            gaps = [1e3 * p[1].elapsed_time(q[0]) for p, q in zip(self.pairs[8:-1], self.pairs[9:]) if q[2] == p[2] + 1]
+            rep.sort()
+            gaps.sort()
+            if rep and gaps:
+                out["gpu_us_per_update_inside_replay"] = {"median": round(rep[len(rep) // 2], 2),
+                                                          "p10": round(rep[len(rep) // 10], 2),
+                                                          "p90": round(rep[9 * len(rep) // 10], 2)}
+                out["gpu_us_between_replays"] = {"median": round(gaps[len(gaps) // 2], 2),
+                                                 "p10": round(gaps[len(gaps) // 10], 2),
+                                                 "p90": round(gaps[9 * len(gaps) // 10], 2),
+                                                 "mean": round(sum(gaps) / len(gaps), 2)}
+                out["updates_per_replay"] = self.pairs[-1][3]
+                P = self.pairs[8:]
+                span = 1e3 * P[0][0].elapsed_time(P[-1][1])
+                ins = sum(1e3 * p[0].elapsed_time(p[1]) for p in P)
+                gp = [(1e3 * p[1].elapsed_time(q[0]), q[4] - p[4], q[5] - p[5]) for p, q in zip(P[:-1], P[1:])]
+                out["stretch"] = {"replays": len(P), "span_us": round(span, 1), "inside_us": round(ins, 1),
+                                  "gaps_us": round(sum(g[0] for g in gp), 1),
+                                  "us_per_update": round(span / (len(P) * P[0][3]), 2),
+                                  "inside_us_per_update_mean": round(ins / (len(P) * P[0][3]), 2),
+                                  "gaps_over_100us": len([g for g in gp if g[0] > 100]),
+                                  "largest_gaps_us_chunks_syncs": [(round(g[0], 1), g[1], g[2])
+                                                                   for g in sorted(gp, reverse=True)[:12]],
+                                  "largest_inside_us_per_update": [round(x, 1) for x in sorted(
+                                      (1e3 * p[0].elapsed_time(p[1]) / p[3] for p in P), reverse=True)[:12]]}
+        with open(os.path.join(args.log_dir, "learner_loop_profile%s.json" % ("" if rank == 0 else "_rank%d" % rank)),
+                  "w") as f:
+            json.dump(out, f)
+        print("[learner %d] loop profile: %s" % (rank, json.dumps(out)), flush=True)
+
+
 def _maybe_peer_fault(args, core, rank, step):
     """inject_fault="peer-withhold:R@S": from its S-th update on, learner rank R's peer all-reduce stops storing its
     gradient slices into its peers (and every rank's waits give up after ~2 ms instead of a second), which is what a
@@ -360,6 +467,10 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
             os.environ["PDA_DP_GRAPH"] = choose_dp_graph_mode(port_offset=0)
         local_device = torch.device("cuda:%d" % ((args.gpu_ind + rank) % max(ngpu, 1)))
         torch.cuda.set_device(local_device)
+        # a GPU learner's host work is launches and small copies: no intra-op thread pool (its workers keep spinning
+        # after every parallel region -- the 6.75 MB snapshot copy of the weight publisher -- on cores the actors and
+        # the runtime's own threads need)
+        torch.set_num_threads(1)
     else:
         local_device = torch.device("cpu")
         torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
@@ -418,7 +529,14 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
                 global_logs.learner_step.value = restored[0]
                 global_logs.actor_step.value = restored[1]
                 print("[learner] resumed from %s at learner step %d" % (_resume_path(args), step))
-    shm_pub = AsyncParamPublisher(global_model, local_device) if rank == 0 else None
+    # How often a snapshot goes to the seqlocked host buffer.  Its readers are the evaluator and -- only with
+    # actor_inference="local" -- the actors; batched inference hosted in the learners reads the live weights.  Every
+    # snapshot's 6.75 MB device-to-host copy stretches the ~2.5 step-graph replays it overlaps 2.8x (measured inside
+    # the job: 8.3 k updates/s at the old 50 snapshots/s, 9.5 k with none), so nobody gets them more often than needed.
+    pub_interval = getattr(args, "param_publish_interval", None)
+    if pub_interval is None:
+        pub_interval = 0.02 if args.actor_inference != "batched" else min(1.0, 0.2 * float(ap.evaluator_freq))
+    shm_pub = AsyncParamPublisher(global_model, local_device, min_interval=float(pub_interval)) if rank == 0 else None
     if shm_pub is not None and restored is not None:
         shm_pub.publish(core.flat_params(), force=True)
     bcast_pub = None
@@ -439,7 +557,10 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
     global_logs.beat("learner", process_ind)
     last_beat = time.time()
     from .actors import _maybe_fault
+    prof = _LoopProfile(local_device) if os.environ.get("PDA_LEARNER_PROF", "0") == "1" else None
     while step < ap.steps:
+        if prof is not None and started:
+            prof.begin()
         now = time.time()
         if now - last_beat > 1.0:           # sign of life for the supervisor's watchdog (launcher.py)
             global_logs.beat("learner", process_ind)
@@ -468,6 +589,8 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
             break
         if hasattr(global_memory, "drain"):
             global_logs.frames_ingested.add(rank, global_memory.drain())
+        if prof is not None and started:
+            prof.lap("drain")
         if not started:
             ready = global_memory.size > ap.learn_start
             started = comm.all_agree(ready)
@@ -481,7 +604,13 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
             if comm.all_agree(behind <= 0) is False:
                 time.sleep(0.0005)
                 continue
+        if prof is not None:
+            prof.before_step(core)
+            prof.mark = time.perf_counter()
         core.step()
+        if prof is not None:
+            prof.after_step()
+            prof.lap("step")
         step += 1
         _maybe_fault(args, "learner", rank, step)
         _maybe_peer_fault(args, core, rank, step)
@@ -494,9 +623,13 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
             if resume_freq and step % resume_freq == 0:
                 save_learner_resume(args, core, step, global_logs.actor_step.value)
             if step % ap.learner_freq == 0:
-                for name, val in core.loss_values().items():
+                if prof is not None:
+                    prof.syncs += 1
+                for name, val in core.loss_values(lagged=True).items():
                     getattr(learner_logs, name).value += val
                 learner_logs.loss_counter.value += 1
+    if prof is not None:
+        prof.dump(args, rank, step)
     if rank == 0:
         if getattr(args, "save_resume", True):
             save_learner_resume(args, core, step, global_logs.actor_step.value)

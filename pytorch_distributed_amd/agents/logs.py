@@ -57,11 +57,35 @@ class ShardedCounter(object):
         return self._lock
 
 
+class PlainValue(object):
+    """A shared scalar with mp.Value's surface (`.value`, `.get_lock()`) whose READS take no lock: an aligned 8-byte
+    load is atomic, and there is one writer at a time (learner rank 0 for `learner_step`; whoever raises `stop` only
+    ever stores True).  `learner_step` used to be an mp.Value: every `.value` read acquires its semaphore, every
+    actor reads it once per env step (`running()`), 100 k times a second in all, and the learner's own
+    `with get_lock(): value += 1` queued behind them -- ~100 us per update, a quarter of the learner's rate inside
+    the job (profiles/r3_node_learner_loop.txt).  The lock still exists for writers that want the reference's idiom."""
+
+    def __init__(self, typecode, initial):
+        self._raw = mp.RawValue(typecode, initial)
+        self._lock = mp.Lock()
+
+    @property
+    def value(self):
+        return self._raw.value
+
+    @value.setter
+    def value(self, v):
+        self._raw.value = v
+
+    def get_lock(self):
+        return self._lock
+
+
 class GlobalLogs(object):
     def __init__(self):
         self.actor_step = ShardedCounter()
-        self.learner_step = mp.Value("l", 0)
-        self.stop = mp.Value("b", False)
+        self.learner_step = PlainValue("l", 0)
+        self.stop = PlainValue("b", False)
         self.frames_ingested = ShardedCounter(64)
         self.heartbeats = mp.RawArray("d", MAX_PROCS)       # time.time() of each process's last sign of life
 

@@ -210,6 +210,7 @@ class DeviceMemory(Memory):
         #    7.4 k updates/s inside the job against 10.4 k alone)
         while self._copying and self._copy_evt[self._copying[0][0]].query():
             d, n = self._copying.pop(0)
+            self.chunks_unpacked = getattr(self, "chunks_unpacked", 0) + 1
             learner_stream.wait_event(self._copy_evt[d])    # complete already: an ordering edge, not a stall
             self.ingest_records(self._slabs[d], n)
             self._unpack_evt[d].record(learner_stream)

@@ -10,7 +10,7 @@
 // Python, no allocator, no per-request launches in the loop:
 //
 //   collect pending slots -> H2D of their rows (merged runs) -> graph[bucket]:
-//       stage idx/eps -> conv1(u8, gathered through idx) -> conv2 -> conv3 -> fc1 split-K
+//       conv1(u8, gathered through the slot indices in mapped host memory) -> conv2 -> conv3 -> fc1 split-K
 //       -> fc2 + epsilon-greedy head writing {action, q[a], max q} into mapped host memory
 //   -> stream sync -> scatter to the slots' out rows -> release-store resp (+ futex wake)
 //
@@ -71,15 +71,14 @@ struct Server {
     std::vector<hipGraphExec_t> graphs;
     // device
     uint8_t* d_obs = nullptr;
-    int* d_idx = nullptr;
-    float* d_eps = nullptr;
-    unsigned long long* d_counter = nullptr;
     bf16_t *a1 = nullptr, *a2 = nullptr, *a3 = nullptr;     // cnn activations / mlp x,h1,h2
     bf16_t* a4 = nullptr;                                   // mlp action rows
     float* h1pre = nullptr;
     // pinned + mapped host
     int* h_idx = nullptr; float* h_eps = nullptr; float* h_out = nullptr; uint8_t* h_stage = nullptr;
+    unsigned long long* h_counter = nullptr;
     int* hd_idx = nullptr; float* hd_eps = nullptr; float* hd_out = nullptr;   // device views of the above
+    unsigned long long* hd_counter = nullptr;
     int out_cols = 0;
     // loop
     std::thread thread;
@@ -90,28 +89,21 @@ struct Server {
     std::vector<uint64_t> req_seen;
 };
 
-__global__ void infer_stage_kernel(const int* h_idx, const float* h_eps, int* d_idx, float* d_eps, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        d_idx[i] = h_idx[i];
-        d_eps[i] = h_eps[i];
-    }
-}
-
 int conv_out(int h, int k, int s) { return (h - k) / s + 1; }
 
 void enqueue_program(Server& S, int n) {
     const InferConfig& c = S.c;
     hipStream_t st = S.stream;
-    hipLaunchKernelGGL(infer_stage_kernel, dim3((n + 255) / 256), dim3(256), 0, st, S.hd_idx, S.hd_eps, S.d_idx,
-                       S.d_eps, n);
+    // The batch's slot indices, epsilons and the RNG counter are read by the kernels straight out of mapped host
+    // memory (a PCIe read per workgroup, under its prologue): no staging launch in front of the network and no counter
+    // launch behind it -- three kernels per batch instead of five, each of which contends with the learner's.
     if (c.kind == 0) {
         int H1 = conv_out(c.H, 8, 4), W1 = conv_out(c.W, 8, 4);
         int H2 = conv_out(H1, 4, 2), W2 = conv_out(W1, 4, 2);
         int H3 = conv_out(H2, 3, 1), W3 = conv_out(W2, 3, 1);
         int F = 64 * H3 * W3;
         const void* frames[1] = {S.d_obs};
-        const void* idx[1] = {S.d_idx};
+        const void* idx[1] = {S.hd_idx};
         const void* w0[1] = {c.w[0]}; const void* b0[1] = {c.b[0]};
         const void* w1[1] = {c.w[1]}; const void* b1[1] = {c.b[1]};
         const void* w2[1] = {c.w[2]}; const void* b2[1] = {c.b[2]};
@@ -139,14 +131,13 @@ void enqueue_program(Server& S, int n) {
         pda_linear_fwd(x3, w3, nullptr, nullptr, o32, 1, n, c.HID, F, F, F, 0, c.HID, ACT_NONE, ks, st);
         ActHeadArgs a;
         a.h1pre = S.h1pre; a.b4 = (const float*)c.b[3]; a.w5 = (const float*)c.w[4]; a.b5 = (const float*)c.b[4];
-        a.eps = S.d_eps; a.out = S.hd_out; a.out_ld = S.out_cols; a.q_out = nullptr;
-        a.B = n; a.HID = c.HID; a.A = c.A; a.seed = c.seed; a.counter = S.d_counter;
+        a.eps = S.hd_eps; a.out = S.hd_out; a.out_ld = S.out_cols; a.q_out = nullptr;
+        a.B = n; a.HID = c.HID; a.A = c.A; a.seed = c.seed; a.counter = S.hd_counter;    // (bumped by the host per batch)
         pda_act_head(&a, st);
-        pda_tick(nullptr, S.d_counter, st);
     } else {
         StageJobs jobs;
         jobs.j[0] = {(const float*)S.d_obs, c.obs_stride / 4, 0, c.D, S.a1, (long)c.Dp, 0, 1.f};
-        pda_mlp_stage(&jobs, 1, S.d_idx, n, c.D, st);
+        pda_mlp_stage(&jobs, 1, S.hd_idx, n, c.D, st);
         const void* x0[1] = {S.a1}; const void* x1[1] = {S.a2}; const void* x2[1] = {S.a3};
         void* o0[1] = {S.a2}; void* o1[1] = {S.a3}; void* o2[1] = {S.a4};
         const void* w0[1] = {c.w[0]}; const void* w1[1] = {c.w[1]}; const void* w2[1] = {c.w[2]};
@@ -196,9 +187,6 @@ bool build(Server& S) {
     if (!ok) return false;
     size_t obs_bytes = (size_t)c.nslots * c.obs_stride;
     dev_alloc(&S.d_obs, obs_bytes, ok);
-    dev_alloc(&S.d_idx, maxb, ok);
-    dev_alloc(&S.d_eps, maxb, ok);
-    dev_alloc(&S.d_counter, 1, ok);
     if (c.kind == 0) {
         int H1 = conv_out(c.H, 8, 4), W1 = conv_out(c.W, 8, 4);
         int H2 = conv_out(H1, 4, 2), W2 = conv_out(W1, 4, 2);
@@ -216,6 +204,7 @@ bool build(Server& S) {
     host_alloc(&S.h_idx, &S.hd_idx, maxb, ok);
     host_alloc(&S.h_eps, &S.hd_eps, maxb, ok);
     host_alloc(&S.h_out, &S.hd_out, (size_t)maxb * S.out_cols, ok);
+    host_alloc(&S.h_counter, &S.hd_counter, 8, ok);
     if (!ok) return false;
     // DMA straight out of the shared-memory mailbox when the runtime lets us pin it
     hipError_t reg = hipHostRegister(c.obs, obs_bytes, hipHostRegisterDefault);
@@ -301,6 +290,7 @@ int serve_once(Server& S, int window_us = 0) {
         for (int k = 0; k < bucket; ++k) S.h_idx[k] = k < n ? k : 0;
     }
     for (int k = 0; k < bucket; ++k) S.h_eps[k] = (c.eps && k < n) ? c.eps[S.ids[k]] : 0.f;
+    S.h_counter[0] += 1;            // the epsilon-greedy draws of this batch (the stream is idle: last batch was waited for)
     HIPCHK(hipGraphLaunch(S.graphs[bi], S.stream));
     HIPCHK(hipStreamSynchronize(S.stream));
     if (!ok) return -1;
@@ -385,9 +375,9 @@ PDA_EXPORT void pda_infer_destroy(void* h) {
     (void)hipStreamSynchronize(S->stream);
     for (hipGraphExec_t g : S->graphs) (void)hipGraphExecDestroy(g);
     if (S->registered) (void)hipHostUnregister(S->c.obs);
-    void* dev[] = {S->d_obs, S->d_idx, S->d_eps, S->d_counter, S->a1, S->a2, S->a3, S->a4, S->h1pre};
+    void* dev[] = {S->d_obs, S->a1, S->a2, S->a3, S->a4, S->h1pre};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {S->h_idx, S->h_eps, S->h_out, S->h_stage};
+    void* host[] = {S->h_idx, S->h_eps, S->h_out, S->h_stage, S->h_counter};
     for (void* p : host) if (p) (void)hipHostFree(p);
     (void)hipStreamDestroy(S->stream);
     delete S;

@@ -259,7 +259,14 @@ class _EngineBase(object):
         if not staged and self.per is not None and self.replay[3] is not None:
             self.replay[3].repair(self.idx, self.B)
 
-    def mean_losses(self):
+    def mean_losses(self, lagged=False):
+        if lagged and self.loss_acc.is_cuda:        # no host synchronisation: one read-out period behind
+            if getattr(self, "_loss_readout", None) is None:
+                from .optim import LaggedReadout
+                self._loss_readout = LaggedReadout(self.loss_acc)
+            vals, n = self._loss_readout.read(self.loss_steps)
+            self.loss_steps = 0
+            return [float(vals.sum()) / n] if self.per_sample_loss else (vals / n).tolist()
         n = max(self.loss_steps, 1)
         vals = [float(self.loss_acc.sum()) / n] if self.per_sample_loss else (self.loss_acc / n).tolist()
         self.loss_acc.zero_()
@@ -741,8 +748,8 @@ class MlpNativeCore(object):
     def flat_params(self):
         return self.engine.online.flat
 
-    def loss_values(self):
-        vals = self.engine.mean_losses()
+    def loss_values(self, lagged=False):
+        vals = self.engine.mean_losses(lagged=lagged)
         if self.kind == "ddpg":
             return {"actor_loss": vals[0], "critic_loss": vals[1]}
         return {"critic_loss": vals[0]}

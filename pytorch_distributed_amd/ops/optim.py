@@ -169,3 +169,36 @@ def polyak_params_(dst_params, src_params, tau):
     for dp, sp, n in runs:
         L.pda_polyak_flat(_vp(dp), _vp(sp), n, float(tau), _stream())
     return True
+
+
+class LaggedReadout(object):
+    """Read a small device accumulator (the learner's loss sums) out WITHOUT a host synchronisation: each call
+    enqueues an asynchronous copy of the accumulator into pinned memory (and its reset, stream-ordered behind the
+    copy) and returns the values of the PREVIOUS call's copy, which has long landed.  The learner loop reads its
+    loss every `learner_freq` updates; a blocking read there drains the whole launch queue and leaves the GPU idle
+    until the host has caught up again (~250 us per read-out inside the job, profiles/r3_node_learner_loop.txt).
+    The first call has nothing older to return and blocks once."""
+
+    def __init__(self, acc):
+        self.acc = acc
+        self.host = [torch.zeros(acc.numel(), dtype=acc.dtype).pin_memory() for _ in range(2)]
+        self.evt = [torch.cuda.Event(), torch.cuda.Event()]
+        self.steps = [0, 0]
+        self.k = 0
+        self.last = None
+
+    def read(self, steps):
+        """-> (accumulator values as a host tensor, number of steps they cover), one call behind."""
+        i = self.k & 1
+        self.host[i].copy_(self.acc.reshape(-1), non_blocking=True)
+        self.acc.zero_()
+        self.evt[i].record()
+        self.steps[i] = int(steps)
+        self.k += 1
+        j = i ^ 1
+        if self.k == 1:
+            self.evt[i].synchronize()
+            j = i
+        else:
+            self.evt[j].synchronize()       # recorded a whole read-out period ago: returns at once
+        return self.host[j].clone(), max(self.steps[j], 1)

@@ -12,3 +12,4 @@ Value = ctx.Value
 Lock = ctx.Lock
 Process = ctx.Process
 RawArray = ctx.RawArray
+RawValue = ctx.RawValue

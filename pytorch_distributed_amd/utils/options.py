@@ -158,7 +158,9 @@ class Params(object):
         # fp32 PyTorch step -- the reference learner is fp32, core/single_processes/dqn_learner.py:63-87);
         # "bf16": plain bf16 operands (fastest; conv gradients within ~10 % of fp32)
         self.precision = "fp32"
-        self.param_sync_freq = 25           # learner publishes weights every this many learner steps
+        self.param_sync_freq = 25           # learner publishes weights every this many learner steps ...
+        self.param_publish_interval = None  # ... but at most once per this many seconds (None: 0.02 with per-actor model
+                                            # copies, min(1, evaluator_freq / 5) when inference is batched on the GPU)
         self.supervise = True               # restart dead actors, stop everything if a learner dies
         self.inject_fault = None            # "actor:1@50" kills actor process 1 at its 50th step, "learner:1@20" learner
                                             # rank 1 after its 20th update, "hang-learner:0@20" makes rank 0 stop

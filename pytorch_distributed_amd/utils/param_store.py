@@ -67,7 +67,9 @@ class AsyncParamPublisher(object):
         if self.cuda:
             self.pinned = self.pinned.pin_memory()
             self.stream = torch.cuda.Stream(device=self.device)
-            self.event = torch.cuda.Event()
+            self.event = torch.cuda.Event(enable_timing=True)
+            self.event0 = torch.cuda.Event(enable_timing=True)
+            self.copy_ms = 0.0
             self.cv = threading.Condition()
             self.stopping = False
             self.thread = threading.Thread(target=self._run, name="param-publisher", daemon=True)
@@ -81,7 +83,12 @@ class AsyncParamPublisher(object):
                     self.cv.wait()
                 if self.stopping and not self.busy:
                     return
-            self.event.synchronize()
+            # (polling, not event.synchronize(): a thread parked inside the runtime's blocking wait while the learner's
+            # step graphs are replaying stretched those replays 2.8x -- 8.3 k instead of 9.5 k updates/s inside the job,
+            # profiles/r3_node_learner_loop.txt)
+            while not self.event.query():
+                time.sleep(0.0003)
+            self.copy_ms += self.event0.elapsed_time(self.event)
             publish_params(self.global_model, self.pinned)
             with self.cv:
                 self.busy = False
@@ -105,6 +112,7 @@ class AsyncParamPublisher(object):
             self.last = now
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.stream):
+                self.event0.record(self.stream)
                 self.pinned.copy_(flat.detach().reshape(-1), non_blocking=True)
                 self.event.record(self.stream)
             self.busy = True
@@ -121,6 +129,8 @@ class AsyncParamPublisher(object):
             self.stopping = True
             self.cv.notify_all()
         self.thread.join(10)
+        print("[publisher] %d snapshots (%d requests skipped), %.3f ms per device-to-host copy"
+              % (self.published, self.skipped, self.copy_ms / max(self.published, 1)), flush=True)
 
 
 @torch.no_grad()
