@@ -69,6 +69,12 @@ def evaluator(process_ind, args, global_logs, evaluator_logs, env_prototype, mod
         print("Saving model " + args.model_name + " ...")
         save_state_dict(local_model, args.model_name)
         print("Saved  model " + args.model_name + ".")
+        # optional "solved": end the job once an evaluation reaches the target score (bench/pong_wallclock.py measures
+        # the wall-clock to that point; the reference only ever stops at `steps`)
+        goal = getattr(ap, "stop_at_eval_reward", None)
+        if goal is not None and nepisodes > 0 and total_reward / nepisodes >= float(goal):
+            print("[evaluator] avg reward %.2f >= %.2f: stopping the job" % (total_reward / nepisodes, float(goal)), flush=True)
+            global_logs.stop.value = True
 
     last_eval_time = time.time()
     while global_logs.running(ap.steps):

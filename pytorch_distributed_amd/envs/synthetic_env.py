@@ -103,3 +103,12 @@ class SyntheticAtariEnv(Env):
             self.frames.append(self.pool[(self.t * 7 + a) % self._POOL])
         self.exp_state1 = self._state()
         return self._get_experience()
+
+
+def make_synthetic_env(args, process_ind=0, num_envs_per_process=1):
+    """EnvsDict["synthetic"]: the built-in pixel games by `game` -- "minipong" (envs/minipong.py: a real horizon,
+    first to 21), "catch" (a 12-step toy), anything else: Atari-shaped noise frames for throughput runs."""
+    if args.game == "minipong":
+        from .minipong import MiniPongEnv
+        return MiniPongEnv(args, process_ind, num_envs_per_process)
+    return SyntheticAtariEnv(args, process_ind, num_envs_per_process)

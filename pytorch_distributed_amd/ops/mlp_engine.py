@@ -701,14 +701,27 @@ class MlpNativeCore(object):
         rank = comm.rank if comm is not None else 0
         seed = args.seed * 7919 + 104729 * rank + 17
         offs = (0, a, a + k, a + 2 * k)
+        precision = str(getattr(args, "precision", "fp32"))
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16', not %r" % (precision,))
+        self.precision = precision
         if kind == "ddpg":
-            self.engine = DdpgMlpEngine(model, target_model, ap.batch_size, lr=ap.lr, weight_decay=ap.weight_decay,
-                                        clip=ap.clip_grad, tau=ap.target_model_update, per=per, seed=seed,
-                                        tail_offsets=offs, leak=getattr(ap, "compat_ddpg_grad_leak", True),
-                                        actor_warmup=getattr(ap, "actor_warmup_steps", 0),
-                                        actor_l2=float(getattr(ap, "actor_preact_l2", 0.0) or 0.0))
+            # precision="fp32" (the default, the reference learner's arithmetic): fp32 operands on the fp32-input MFMA
+            # (ops/mlp_f32_engine.py); "bf16": the fused bf16 kernel
+            if precision == "fp32":
+                from .mlp_f32_engine import DdpgMlpEngineF32 as engine_cls
+            else:
+                engine_cls = DdpgMlpEngine
+            self.engine = engine_cls(model, target_model, ap.batch_size, lr=ap.lr, weight_decay=ap.weight_decay,
+                                     clip=ap.clip_grad, tau=ap.target_model_update, per=per, seed=seed,
+                                     tail_offsets=offs, leak=getattr(ap, "compat_ddpg_grad_leak", True),
+                                     actor_warmup=getattr(ap, "actor_warmup_steps", 0),
+                                     actor_l2=float(getattr(ap, "actor_preact_l2", 0.0) or 0.0))
             assert self.engine.A == a
         else:
+            if precision != "bf16":
+                # the MLP-DQN engine multiplies bf16 operands; it is not used when fp32 was asked for
+                raise ValueError("the native dqn-mlp engine is bf16-only: precision=%r needs compute='torch'" % precision)
             self.engine = DqnMlpEngine(model, target_model, ap.batch_size, lr=ap.lr, weight_decay=ap.weight_decay,
                                        clip=ap.clip_grad, double=ap.enable_double,
                                        target_update=ap.target_model_update, per=per, seed=seed, tail_offsets=offs)
@@ -756,9 +769,21 @@ class MlpNativeCore(object):
 
 
 def make_mlp_native_core(kind, args, model, target_model, memory, comm):
+    """The native core for an MLP agent, or None when the caller should use the fp32 torch core (which is how
+    precision='fp32' is honoured for dqn-mlp under compute='auto': never by silently running bf16)."""
+    precision = str(getattr(args, "precision", "fp32"))
+    if precision not in ("fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16', not %r" % (precision,))
     if kind == "ddpg" and args.model_type == "ddpg-mlp":
         return MlpNativeCore("ddpg", args, model, target_model, memory, comm)
     if kind == "dqn" and args.model_type == "dqn-mlp":
+        if precision != "bf16":
+            if getattr(args, "compute", "auto") == "native":
+                raise ValueError("compute='native' with precision='fp32' is not available for dqn-mlp (its native engine "
+                                 "is bf16-only): use precision='bf16' or compute='auto' / 'torch'")
+            print("[learner] dqn-mlp at precision=fp32: using the fp32 torch core (the native MLP-DQN engine is "
+                  "bf16-only; precision=bf16 selects it)", flush=True)
+            return None
         try:
             return MlpNativeCore("dqn", args, model, target_model, memory, comm)
         except ValueError:

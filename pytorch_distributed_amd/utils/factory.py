@@ -9,7 +9,7 @@ from ..agents.learners import dqn_learner, ddpg_learner
 from ..agents.evaluators import evaluator
 from ..agents.testers import tester
 from ..envs.atari_env import make_atari_env, AtariEnv
-from ..envs.synthetic_env import SyntheticAtariEnv
+from ..envs.synthetic_env import SyntheticAtariEnv, make_synthetic_env
 from ..envs.pendulum_env import PendulumEnv, ChainEnv, CountingEnv
 from ..memories.shared_memory import SharedMemory
 from ..memories.device_memory import DeviceMemory
@@ -30,7 +30,7 @@ TestersDict = {"dqn": tester, "ddpg": tester}
 
 EnvsDict = {"atari": make_atari_env,        # ALE when installed, synthetic frames otherwise
             "atari-ale": AtariEnv,          # ALE or ImportError
-            "synthetic": SyntheticAtariEnv,
+            "synthetic": make_synthetic_env,    # noise frames | game="catch" | game="minipong"
             "pendulum": PendulumEnv,
             "chain": ChainEnv,
             "counting": CountingEnv}

@@ -32,6 +32,7 @@ CONFIGS = [
     ["dqn",  "synthetic", "pong",      "device-per", "dqn-cnn"],   # 5 large-batch (4096) prioritized DQN
     ["dqn",  "chain",     "chain",     "shared",     "dqn-mlp"],   # 6 tiny learnable task for sanity tests
     ["ddpg", "pendulum",  "pendulum",  "device",     "ddpg-mlp"],  # 7 DDPG with HBM replay + native kernels
+    ["dqn",  "synthetic", "minipong",  "device",     "dqn-cnn"],   # 8 row 2 on the built-in pixel Pong (envs/minipong.py)
 ]
 
 # per-config presets applied after the defaults (dotted keys reach nested params)
@@ -68,6 +69,17 @@ PRESETS = {
     #                                  critic gradients push into saturation has dQ/da (1 - a^2) ~ 0 and never comes
     #                                  back.  The penalty's gradient does not pass through tanh': 8 of 8 seeds.
     # Not needed (measured): reward scaling, separate actor/critic rates, a larger tau, critic-only warm-up (hurts).
+    # 8 = the reference's README Pong setting (8 actors, n-step 5, every hyper-parameter as shipped) on MiniPong
+    # (/root/reference/utils/options.py:112-141), with two additions that the reference's own speed made unnecessary:
+    #   num_envs_per_actor 4           the learner here is ~27x faster than the reference's; the 8 actor processes
+    #                                  keep up by stepping 4 envs each behind one batched inference request per env
+    #   max_replay_ratio 1/16          one update per 16 env steps = 8 samples per transition at batch 128, the replay
+    #                                  intensity of the classic DQN recipe (batch 32 every 4 steps) and about the
+    #                                  reference's own emergent ratio.  Uncoupled, the native learner runs 0.3 updates
+    #                                  per env step and the evaluation score peaks at +14 and wanders between -8 and +14
+    #                                  (profiles/r3_minipong_wallclock.txt); coupled it reaches +20 in ~10 s.
+    8: {"num_actors": 8, "agent_params.nstep": 5, "actor_inference": "batched", "num_envs_per_actor": 4,
+        "agent_params.max_replay_ratio": 0.0625},
     7: {"num_actors": 8, "agent_params.nstep": 1, "agent_params.lr": 1e-3,
         "agent_params.compat_ddpg_grad_leak": False, "agent_params.max_replay_ratio": 1.0,
         "agent_params.min_replay_ratio": 1.0, "agent_params.actor_sync_freq": 50,
@@ -269,6 +281,7 @@ class AgentParams(Params):
         self.max_replay_ratio = 0.0     # cap on learner updates per actor env step (0: none, as in the reference)
         self.min_replay_ratio = 0.0     # floor on the same ratio: actors wait for the learner (0: none, as in the reference)
         self.poll_interval = 5.0        # logger/evaluator wake-up period (secs; the reference hard-codes 5)
+        self.stop_at_eval_reward = None # end the job once an evaluation's average reward reaches this (None: run all `steps`)
         if self.agent_type == "dqn":
             self.clip_grad = np.inf
             self.actor_sync_freq = 100

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--replay", type=int, default=100000)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--phases", action="store_true", help="print the fused kernel's phase timeline (wall_clock64 stamps)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                    help="bf16: fused bf16 kernel (csrc/mlp_fused.hip); fp32: fp32-input MFMA job lists (csrc/mlp_f32.hip)")
     a = ap.parse_args()
     from pytorch_distributed_amd import ops
     ops.require_native()
@@ -37,7 +39,11 @@ def main():
     D, A, n, B = a.obs, a.act, a.replay, a.batch
     model = DdpgMlpModel(opt.model_params, 1.0, (1, D), A, A).cuda()
     target = DdpgMlpModel(opt.model_params, 1.0, (1, D), A, A).cuda()
-    e = eng.DdpgMlpEngine(model, target, B, lr=1e-3, tau=1e-3, leak=False, tail_offsets=(0, A, A + 1, A + 2), seed=1)
+    if a.precision == "fp32":
+        from pytorch_distributed_amd.ops.mlp_f32_engine import DdpgMlpEngineF32 as engine_cls
+    else:
+        engine_cls = eng.DdpgMlpEngine
+    e = engine_cls(model, target, B, lr=1e-3, tau=1e-3, leak=False, tail_offsets=(0, A, A + 1, A + 2), seed=1)
     s0, s1 = torch.randn(n, D, device="cuda"), torch.randn(n, D, device="cuda")
     tails = torch.zeros(n, A + 4, device="cuda")
     tails[:, :A] = torch.rand(n, A, device="cuda") * 2 - 1
@@ -56,7 +62,7 @@ def main():
         prog.step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if a.phases and e.fused:
+    if a.phases and e.fused and a.precision == "bf16":
         st = e.prof.cpu().tolist()
         t0_ = st[31]
         names = ["zero-lds", "stage", "actor.0", "actor.2", "actor.4+critic.0", "critic.1", "head", "dh2", "dcat",
@@ -68,7 +74,7 @@ def main():
             prev = m
         print("phase %-18s %6.2f us   total %6.2f us (100 MHz wall clock)" % ("spill", (st[30] - prev) / 100.0,
                                                                             (st[30] - t0_) / 100.0))
-    print(json.dumps({"bench": "ddpg_mlp_step", "fused": bool(e.fused), "batch": B, "obs": D, "act": A,
+    print(json.dumps({"bench": "ddpg_mlp_step", "precision": a.precision, "fused": bool(e.fused), "batch": B, "obs": D, "act": A,
                       "graph_steps": prog.graph_steps, "hip_graph": not a.no_graph,
                       "us_per_step": round(1e6 * dt / a.steps, 2), "updates_per_sec": round(a.steps / dt, 1),
                       "final_critic_loss": e.mean_losses()[1]}), flush=True)
