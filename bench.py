@@ -82,6 +82,10 @@ def parse_args(argv=None):
     ap.add_argument("--node-actors", type=int, default=8)
     ap.add_argument("--node-envs-per-actor", type=int, default=2)
     ap.add_argument("--node-timeout", type=float, default=240.0)
+    ap.add_argument("--ddpg", default="auto", choices=["auto", "on", "off"],
+                    help="also time the Distributed-DDPG learner step (config 7 shapes: 3-dim obs, 1-dim action, batch "
+                         "64, HBM replay) on the fp32 job-list engine and the fused bf16 engine: \"ddpg_value\" "
+                         "(fp32, the reference's precision) and \"ddpg_bf16_value\", updates/s (auto: 1 GPU, native)")
     ap.add_argument("--launcher", action="store_true", help="start the rank(s) as child processes even for --gpus 1")
     ap.add_argument("--launch-timeout", type=float, default=900.0)
     return ap.parse_args(argv)
@@ -201,6 +205,21 @@ def run_node_job(a, precision, device):
         return {"error": "node job printed no result (exit %s)" % p.returncode}
     except Exception as exc:
         return {"error": repr(exc)}
+
+
+def run_ddpg_step(precision, timeout=120.0):
+    """tools/bench_mlp_step.py in a child process -> its JSON line (dict), or {"error": ...}."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_mlp_step.py"), "--precision", precision,
+           "--steps", "20000", "--warmup", "500"]
+    try:
+        p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "ddpg step bench did not finish within %.0f s" % timeout}
+    for line in reversed(p.stdout.decode(errors="replace").splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return {"error": "ddpg step bench printed no result (exit %s): %s" % (p.returncode,
+                                                                          p.stderr.decode(errors="replace")[-300:])}
 
 
 def timed_windows(core, comm, steps, min_time, max_windows, sync, reduce_max):
@@ -430,6 +449,19 @@ def run_rank(a):
         if use_cuda:
             torch.cuda.empty_cache()
         out["node"] = run_node_job(a, precisions[0], device)
+    if rank == 0 and (a.ddpg == "on" or (a.ddpg == "auto" and use_cuda and world == 1 and a.compute == "native")):
+        # the second agent family (reference core/single_processes/ddpg_learner.py): one learner update = actor +
+        # critic forward/backward, both Adam updates, both Polyak target updates, on HBM-resident replay
+        for key, prec in (("ddpg_value", "fp32"), ("ddpg_bf16_value", "bf16")):
+            r = run_ddpg_step(prec)
+            out[key] = r.get("updates_per_sec")
+            out[key.replace("value", "us_per_step")] = r.get("us_per_step")
+            if "error" in r:
+                out[key + "_error"] = r["error"]
+        out["ddpg_config"] = {"model": "ddpg-mlp (actor 3-300-200-1, critic 3-400 | 401-300-1)", "batch": 64,
+                              "replay": "HBM-resident, uniform", "unit": "updates/s",
+                              "dtype": {"ddpg_value": "fp32 (v_mfma_f32_16x16x4_f32: exact fp32 products and sums)",
+                                        "ddpg_bf16_value": "bf16 operands, fp32 accumulate"}}
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -95,8 +95,10 @@ __device__ __forceinline__ bool row_mode(const SegEntry& s) {
 }
 // flags bit 1: "fine" flat chunks of 64 elements (segments whose gradient is summed from many split-K slabs
 // inside the optimizer): a lane per element, the slices dealt over the 4 waves of the workgroup
+// flags bit 2: "medium" flat chunks of 256 elements, one per thread: a single memory round trip per workgroup (small
+// models, where the optimizer launch is latency- and not bandwidth-bound; 2048-element chunks are 8 dependent trips)
 __device__ __forceinline__ int chunk_len(const SegEntry& s) {
-    return row_mode(s) ? s.cols : ((s.flags & 2) ? 64 : OPT_CHUNK);
+    return row_mode(s) ? s.cols : ((s.flags & 2) ? 64 : (s.flags & 4) ? 256 : OPT_CHUNK);
 }
 
 // gradient element e (kernel order within segment seg): the flat buffer, or the sum of the split-K slabs

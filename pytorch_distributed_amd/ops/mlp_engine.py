@@ -138,8 +138,9 @@ class MlpWeights(object):
     """Flat fp32 parameters of one network + zero-padded bf16 shadows [N][pad8(K)] of every
     matrix that feeds an MFMA GEMM.  Gradients/moments use the same [N][K] order."""
 
-    def __init__(self, model, layers, with_grad, fp32_only=(), transposed=()):
-        """transposed: layers that also keep a bf16 copy [K][pad8(N)] behind the row-major shadows (the fused
+    def __init__(self, model, layers, with_grad, fp32_only=(), transposed=(), opt_chunk=None):
+        """opt_chunk=256: the optimizer walks these segments one element per thread (SegmentTable "medium" chunks).
+        transposed: layers that also keep a bf16 copy [K][pad8(N)] behind the row-major shadows (the fused
         backward's B operand, csrc/mlp_fused.hip); the optimizer launch maintains it (AdamExtras.tinfo)."""
         self.model = model
         self.flat = model.flatten_(with_grad=with_grad)
@@ -165,7 +166,7 @@ class MlpWeights(object):
             woff, _ = segs[name + ".weight"]
             boff, _ = segs[name + ".bias"]
             n, k, kp = shapes[name]
-            ent = {"start": woff, "count": n * k, "cols": k}
+            ent = {"start": woff, "count": n * k, "cols": k, "medium": opt_chunk == 256}
             if name not in fp32_only:
                 ent.update(C=1, P=k, shadow_off=soff, shadow_ld=kp, shadow=True)
                 self.w[name] = self.shadow[soff:soff + n * kp].view(n, kp)
@@ -174,7 +175,7 @@ class MlpWeights(object):
             self.b[name] = self.flat[boff:boff + n]
             self.off[name] = (woff, n * k, boff, n)
             entries.append(ent)
-            entries.append({"start": boff, "count": n})
+            entries.append({"start": boff, "count": n, "medium": opt_chunk == 256})
             covered += n * k + n
         assert covered == self.flat.numel(), "layer list does not cover the model's parameters"
         self.table = SegmentTable(entries, dev)

@@ -37,11 +37,12 @@ class SegmentTable(object):
         for si, e in enumerate(entries):
             rows.append([e["start"], e["count"], e.get("cols", e["count"]), e.get("C", 1),
                          e.get("P", e.get("cols", e["count"])), e.get("shadow_off", 0), e.get("shadow_ld", 0),
-                         (1 if e.get("shadow", False) else 0) | (2 if e.get("fine", False) else 0),
+                         (1 if e.get("shadow", False) else 0) | (2 if e.get("fine", False) else 0)
+                         | (4 if e.get("medium", False) else 0),
                          e.get("tr_off", 0), e.get("tr_ld", 0)])     # transposed shadow copy (csrc/optim.h SegEntry)
             cols, C, P = rows[-1][2], rows[-1][3], rows[-1][4]
             row_mode = bool(e.get("shadow", False)) and C > 1 and (P | 1) * C <= OPT_ROW_LDS
-            step = cols if row_mode else (64 if e.get("fine", False) else OPT_CHUNK)
+            step = cols if row_mode else (64 if e.get("fine", False) else 256 if e.get("medium", False) else OPT_CHUNK)
             for first in range(0, e["count"], step):       # one row per block | flat chunks
                 chunks.append([si, first])
         self.segs = torch.tensor(rows, dtype=torch.int32).to(device)
