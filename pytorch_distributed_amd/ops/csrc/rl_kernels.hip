@@ -5,7 +5,7 @@
 #include "optim.h"
 
 // ----------------------------------------------------------------------------
-// DQN head.  One wave64 per sample; the 512-wide hidden row is 8 values per lane.
+// DQN head.  One workgroup (4 waves) per sample; the 512-wide hidden row is 2 values per thread.
 //   h      = relu(h1pre + b4)                    (fc1 split-K sums arrive as fp32)
 //   q      = W5 h + b5                           (fp32 master weights, A <= 32 actions)
 //   y      = r + gamma^n * max_a q_tgt(s_n)[a] * (1 - done)      (double: a* from online(s_n))
@@ -33,98 +33,117 @@ struct DqnHeadArgs {
     int h1_slices; long h1_slice_stride;
 };
 
+// One WORKGROUP (4 waves) per sample: thread t owns hidden columns t PER .. t PER + PER - 1 (PER = HID / 256).
+// The kernel is a latency chain, not a throughput problem (128 samples, ~50 KB each way), so everything that does not
+// depend on other data is requested in the first instructions -- the index first, so that the tail record can follow
+// as soon as it lands, then every split-K slab slice, both bias rows and the first 8 rows of both W5 -- and the wave
+// waits once.  (One wave per sample with the loads issued where they were used was 5-6 dependent round trips: 8.6 us.)
+template <int PER>
+__device__ __forceinline__ void ldv(const float* src, float (&v)[PER]) {
+    if constexpr (PER == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(src);
+        v[0] = t.x; v[1] = t.y;
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) v[j] = src[j];
+    }
+}
+
 template <int HID>
 __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
-    constexpr int PER = HID / 64;       // values per lane (8 for 512)
-    const int wpb = blockDim.x >> 6;    // waves per workgroup: 1 for small batches (one sample per CU), else 4
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int b = blockIdx.x * wpb + wave;
+    constexpr int PER = HID / 256;
+    __shared__ float part[4][3][32];        // [wave][online(s0) | target(s_n) | online(s_n)][action]
+    __shared__ float qfin[3][32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (p.rng_counter) *p.rng_counter += 1;     // the sampler of the NEXT step draws a fresh stream
         if (p.opt_step) *p.opt_step += 1;           // Adam of THIS step sees t = old + 1
     }
-    if (b >= p.B) return;
-    long row = (long)b * HID + lane * PER;
-
-    // The replay row (index -> tail record -> action -> that action's W5 row) is a chain of three dependent
-    // global loads, and a wave issues in order: every s_waitcnt on that chain also holds back the loads behind it.
-    // So the chain is interleaved with the independent work instead of run ahead of it: the index load goes out
-    // first and is only consumed after the hidden-row sums (whose loads are then already in flight), the tail
-    // record is fetched before the fc2 dot products and consumed after them, and the action's W5 row is re-read
-    // at the very end, when this wave has just pulled all of W5 through its L1.
+    const int col = tid * PER;
+    const long row = (long)b * HID + col;
+    const bool dbl = p.h1pre_on1 != nullptr;
+    // ---- requests
     const int ridx = p.idx ? p.idx[b] : b;
     const float w = p.isw ? p.isw[b] : 1.f;
-
-    float h0[PER], ht[PER], hd[PER];
-    if (p.h1_slices > 0) {
-        // slabs: PER consecutive floats per lane and slice (16-byte loads), summed in slice order
-        typedef float vecf __attribute__((ext_vector_type(PER)));
-        vecf a0 = {}, at = {}, ad = {};
-        // four slices per round trip: the loads of a group are all issued before the first add (one slice per
-        // iteration was a chain of h1_slices dependent memory latencies on 128 waves -- most of this kernel's 9 us)
-        int sl = 0;
-        for (; sl + 4 <= p.h1_slices; sl += 4) {
-            vecf v0[4], vt[4], vd[4];
+    float b4o[PER], b4t[PER];
+    ldv<PER>(p.b4_on + col, b4o);
+    ldv<PER>(p.b4_tg + col, b4t);
+    float a0[PER], at[PER], ad[PER];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long o = (long)(sl + u) * p.h1_slice_stride + row;
-                v0[u] = *reinterpret_cast<const vecf*>(p.h1pre_on0 + o);
-                vt[u] = *reinterpret_cast<const vecf*>(p.h1pre_tg1 + o);
-                if (p.h1pre_on1) vd[u] = *reinterpret_cast<const vecf*>(p.h1pre_on1 + o);
-            }
+    for (int j = 0; j < PER; ++j) { a0[j] = 0.f; at[j] = 0.f; ad[j] = 0.f; }
+    const int nsl = max(p.h1_slices, 1);
+    const long sstride = p.h1_slices > 0 ? p.h1_slice_stride : 0;
+    float v0[8][PER], vt[8][PER], vd[8][PER];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {       // slice order: bit-reproducible
-                a0 += v0[u];
-                at += vt[u];
-                if (p.h1pre_on1) ad += vd[u];
-            }
-        }
-        for (; sl < p.h1_slices; ++sl) {
-            const long o = (long)sl * p.h1_slice_stride + row;
-            a0 += *reinterpret_cast<const vecf*>(p.h1pre_on0 + o);
-            at += *reinterpret_cast<const vecf*>(p.h1pre_tg1 + o);
-            if (p.h1pre_on1) ad += *reinterpret_cast<const vecf*>(p.h1pre_on1 + o);
-        }
+    for (int u = 0; u < 8; ++u) {           // the first 8 slices (fc1 forward at batch 128 makes 8)
+        const long o = (long)min(u, nsl - 1) * sstride + row;
+        ldv<PER>(p.h1pre_on0 + o, v0[u]);
+        ldv<PER>(p.h1pre_tg1 + o, vt[u]);
+        if (dbl) ldv<PER>(p.h1pre_on1 + o, vd[u]);
+    }
+    float w_on8[8][PER], w_tg8[8][PER];
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            h0[j] = fmaxf(a0[j] + p.b4_on[lane * PER + j], 0.f);
-            ht[j] = fmaxf(at[j] + p.b4_tg[lane * PER + j], 0.f);
-            hd[j] = p.h1pre_on1 ? fmaxf(ad[j] + p.b4_on[lane * PER + j], 0.f) : 0.f;
-        }
-    } else {
+    for (int u = 0; u < 8; ++u) {
+        const long o = (long)min(u, p.A - 1) * HID + col;
+        ldv<PER>(p.w5_on + o, w_on8[u]);
+        ldv<PER>(p.w5_tg + o, w_tg8[u]);
+    }
+    const float b5o = tid < p.A ? p.b5_on[tid] : 0.f, b5t = tid < p.A ? p.b5_tg[tid] : 0.f;
+    const float* tl = p.tails + (long)ridx * p.tail_ld;     // (waits for the index only: it was requested first)
+    const float t_act = tl[p.off_action], t_rew = tl[p.off_reward], t_gam = tl[p.off_gamma], t_term = tl[p.off_term];
+    // ---- hidden rows: slices added in slice order (bit-reproducible)
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            h0[j] = fmaxf(p.h1pre_on0[row + j] + p.b4_on[lane * PER + j], 0.f);
-            ht[j] = fmaxf(p.h1pre_tg1[row + j] + p.b4_tg[lane * PER + j], 0.f);
-            hd[j] = p.h1pre_on1 ? fmaxf(p.h1pre_on1[row + j] + p.b4_on[lane * PER + j], 0.f) : 0.f;
-            p.h1pre_on0[row + j] = 0.f;
-            p.h1pre_tg1[row + j] = 0.f;
-            if (p.h1pre_on1) p.h1pre_on1[row + j] = 0.f;
+    for (int u = 0; u < 8; ++u) {
+        if (u < nsl) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) { a0[j] += v0[u][j]; at[j] += vt[u][j]; if (dbl) ad[j] += vd[u][j]; }
         }
     }
-
-    const float* tl = p.tails + (long)ridx * p.tail_ld;
-    const float t_act = tl[p.off_action], t_rew = tl[p.off_reward], t_gam = tl[p.off_gamma], t_term = tl[p.off_term];
-
-    // lane a keeps q(.)[a]: no runtime-indexed arrays (they would live in scratch).  Actions go in
-    // groups of 8 with the 24 dot products formed first and reduced together, so the shuffles of
-    // independent reductions overlap (one wave per sample = nothing else hides their latency).
-    float myq0 = 0.f, myqt = 0.f, best_t = -INFINITY, best_d = -INFINITY;
-    int arg_d = 0;
-    for (int a0 = 0; a0 < p.A; a0 += 8) {
+    for (int sl = 8; sl < nsl; ++sl) {
+        const long o = (long)sl * sstride + row;
+        float x0[PER], xt[PER], xd[PER];
+        ldv<PER>(p.h1pre_on0 + o, x0);
+        ldv<PER>(p.h1pre_tg1 + o, xt);
+        if (dbl) ldv<PER>(p.h1pre_on1 + o, xd);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { a0[j] += x0[j]; at[j] += xt[j]; if (dbl) ad[j] += xd[j]; }
+    }
+    if (p.h1_slices <= 0) {     // one atomically accumulated buffer: zero it for the next step
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            p.h1pre_on0[row + j] = 0.f;
+            p.h1pre_tg1[row + j] = 0.f;
+            if (dbl) p.h1pre_on1[row + j] = 0.f;
+        }
+    }
+    float h0[PER], ht[PER], hd[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        h0[j] = fmaxf(a0[j] + b4o[j], 0.f);
+        ht[j] = fmaxf(at[j] + b4t[j], 0.f);
+        hd[j] = dbl ? fmaxf(ad[j] + b4o[j], 0.f) : 0.f;
+    }
+    // ---- fc2: per-wave partial dot products, 8 actions at a time (their reductions overlap), combined through LDS
+    for (int g0 = 0; g0 < p.A; g0 += 8) {
         float s0[8], st[8], sd[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            s0[u] = 0.f; st[u] = 0.f; sd[u] = 0.f;
-            if (a0 + u < p.A) {
-                const float* w_on = p.w5_on + (long)(a0 + u) * HID + lane * PER;
-                const float* w_tg = p.w5_tg + (long)(a0 + u) * HID + lane * PER;
+            float won[PER], wtg[PER];
+            if (g0 == 0) {
 #pragma unroll
-                for (int j = 0; j < PER; ++j) {
-                    s0[u] += h0[j] * w_on[j];
-                    st[u] += ht[j] * w_tg[j];
-                    sd[u] += hd[j] * w_on[j];
-                }
+                for (int j = 0; j < PER; ++j) { won[j] = w_on8[u][j]; wtg[j] = w_tg8[u][j]; }
+            } else {
+                const long o = (long)min(g0 + u, p.A - 1) * HID + col;
+                ldv<PER>(p.w5_on + o, won);
+                ldv<PER>(p.w5_tg + o, wtg);
+            }
+            s0[u] = 0.f; st[u] = 0.f; sd[u] = 0.f;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                s0[u] += h0[j] * won[j];
+                st[u] += ht[j] * wtg[j];
+                sd[u] += hd[j] * won[j];
             }
         }
 #pragma unroll
@@ -133,68 +152,86 @@ __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
             for (int u = 0; u < 8; ++u) {
                 s0[u] += __shfl_xor(s0[u], o, 64);
                 st[u] += __shfl_xor(st[u], o, 64);
-                sd[u] += __shfl_xor(sd[u], o, 64);
+                if (dbl) sd[u] += __shfl_xor(sd[u], o, 64);
             }
         }
+        if (lane == 0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            int a = a0 + u;
-            if (a < p.A) {
-                float q0 = s0[u] + p.b5_on[a], qt = st[u] + p.b5_tg[a], qd = sd[u] + p.b5_on[a];
-                if (lane == a) { myq0 = q0; myqt = qt; }
-                best_t = fmaxf(best_t, qt);
-                if (qd > best_d) { best_d = qd; arg_d = a; }
+            for (int u = 0; u < 8; ++u) {
+                if (g0 + u < p.A) { part[wave][0][g0 + u] = s0[u]; part[wave][1][g0 + u] = st[u]; part[wave][2][g0 + u] = sd[u]; }
             }
         }
     }
-    float next_q = p.h1pre_on1 ? __shfl(myqt, arg_d, 64) : best_t;
+    __syncthreads();
+    if (tid < p.A) {
+        qfin[0][tid] = ((part[0][0][tid] + part[1][0][tid]) + (part[2][0][tid] + part[3][0][tid])) + b5o;
+        qfin[1][tid] = ((part[0][1][tid] + part[1][1][tid]) + (part[2][1][tid] + part[3][1][tid])) + b5t;
+        qfin[2][tid] = ((part[0][2][tid] + part[1][2][tid]) + (part[2][2][tid] + part[3][2][tid])) + b5o;
+    }
+    __syncthreads();
+    float best_t = -INFINITY, best_d = -INFINITY;
+    int arg_d = 0;
+    for (int a = 0; a < p.A; ++a) {
+        best_t = fmaxf(best_t, qfin[1][a]);
+        if (qfin[2][a] > best_d) { best_d = qfin[2][a]; arg_d = a; }
+    }
+    const float next_q = dbl ? qfin[1][arg_d] : best_t;
     const int act = min(max((int)t_act, 0), p.A - 1);
     float wa[PER];
-    {
-        const float* w_act = p.w5_on + (long)act * HID + lane * PER;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) wa[j] = w_act[j];
+    for (int j = 0; j < PER; ++j) wa[j] = 0.f;
+    if (act < 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u == act) {
+#pragma unroll
+                for (int j = 0; j < PER; ++j) wa[j] = w_on8[u][j];
+            }
+    } else {
+        ldv<PER>(p.w5_on + (long)act * HID + col, wa);
     }
-
-    float y = t_rew + t_gam * next_q * (1.f - t_term);
-    float td = __shfl(myq0, act, 64) - y;
-    float dqa = 2.f * w * td / (float)p.B;
-
-    uint32_t hw[PER / 2], dw[PER / 2];
+    const float y = t_rew + t_gam * next_q * (1.f - t_term);
+    const float td = qfin[0][act] - y;
+    const float dqa = 2.f * w * td / (float)p.B;
+    float dv[PER];
 #pragma unroll
-    for (int j = 0; j < PER; j += 2) {
-        hw[j / 2] = pack2bf(h0[j], h0[j + 1]);
-        dw[j / 2] = pack2bf(h0[j] > 0.f ? dqa * wa[j] : 0.f, h0[j + 1] > 0.f ? dqa * wa[j + 1] : 0.f);
-    }
-    uint32_t* ho = reinterpret_cast<uint32_t*>(p.h1_on0 + row);
-    uint32_t* dout = reinterpret_cast<uint32_t*>(p.dh1 + row);
+    for (int j = 0; j < PER; ++j) dv[j] = h0[j] > 0.f ? dqa * wa[j] : 0.f;
+    if constexpr (PER == 2) {
+        const uint32_t hw = pack2bf(h0[0], h0[1]), dw = pack2bf(dv[0], dv[1]);
+        *reinterpret_cast<uint32_t*>(p.h1_on0 + row) = hw;
+        *reinterpret_cast<uint32_t*>(p.dh1 + row) = dw;
+        if (p.h1_plane) {       // residuals of the two rows: x - bf16(x), itself rounded to bf16
+            *reinterpret_cast<uint32_t*>(p.h1_on0 + p.h1_plane + row) =
+                pack2bf(h0[0] - bf2f((bf16_t)(hw & 0xffffu)), h0[1] - bf2f((bf16_t)(hw >> 16)));
+            *reinterpret_cast<uint32_t*>(p.dh1 + p.dh1_plane + row) =
+                pack2bf(dv[0] - bf2f((bf16_t)(dw & 0xffffu)), dv[1] - bf2f((bf16_t)(dw >> 16)));
+        }
+    } else {
 #pragma unroll
-    for (int j = 0; j < PER / 2; ++j) { ho[j] = hw[j]; dout[j] = dw[j]; }
-    if (p.h1_plane) {       // residuals of the two rows: x - bf16(x), itself rounded to bf16
-        uint32_t* hl = reinterpret_cast<uint32_t*>(p.h1_on0 + p.h1_plane + row);
-        uint32_t* dl = reinterpret_cast<uint32_t*>(p.dh1 + p.dh1_plane + row);
-#pragma unroll
-        for (int j = 0; j < PER; j += 2) {
-            float d0 = h0[j] > 0.f ? dqa * wa[j] : 0.f, d1 = h0[j + 1] > 0.f ? dqa * wa[j + 1] : 0.f;
-            hl[j / 2] = pack2bf(h0[j] - bf2f((bf16_t)(hw[j / 2] & 0xffffu)), h0[j + 1] - bf2f((bf16_t)(hw[j / 2] >> 16)));
-            dl[j / 2] = pack2bf(d0 - bf2f((bf16_t)(dw[j / 2] & 0xffffu)), d1 - bf2f((bf16_t)(dw[j / 2] >> 16)));
+        for (int j = 0; j < PER; ++j) {
+            const bf16_t hh = f2bf(h0[j]), dh = f2bf(dv[j]);
+            p.h1_on0[row + j] = hh;
+            p.dh1[row + j] = dh;
+            if (p.h1_plane) {
+                p.h1_on0[p.h1_plane + row + j] = f2bf(h0[j] - bf2f(hh));
+                p.dh1[p.dh1_plane + row + j] = f2bf(dv[j] - bf2f(dh));
+            }
         }
     }
-
-    if (lane < p.dq_ld) {
-        const float dv = lane == act ? dqa : 0.f;
-        const bf16_t dh = f2bf(dv);
-        p.dq[(long)b * p.dq_ld + lane] = dh;
-        if (p.dq_plane) p.dq[p.dq_plane + (long)b * p.dq_ld + lane] = f2bf(dv - bf2f(dh));
+    if (tid < p.dq_ld) {
+        const float dq = tid == act ? dqa : 0.f;
+        const bf16_t dh = f2bf(dq);
+        p.dq[(long)b * p.dq_ld + tid] = dh;
+        if (p.dq_plane) p.dq[p.dq_plane + (long)b * p.dq_ld + tid] = f2bf(dq - bf2f(dh));
     }
-    if (lane < p.A && p.q_out) p.q_out[(long)b * p.A + lane] = myq0;
-    if (lane == 0) {
+    if (tid < p.A && p.q_out) p.q_out[(long)b * p.A + tid] = qfin[0][tid];
+    if (tid == 0) {
         if (p.td_out) p.td_out[b] = td;
         // per-sample loss accumulator (summed on the host side when the logger asks): 128 fp32
         // atomics on one address serialise memory-side and were half of this kernel's time
         p.loss_sum[b] += w * td * td / (float)p.B;
         if (p.leaf_sum) {
-            float leaf = __powf(fabsf(td) + p.prio_eps, p.prio_alpha);
+            const float leaf = __powf(fabsf(td) + p.prio_eps, p.prio_alpha);
             p.leaf_sum[ridx] = leaf;
             p.leaf_min[ridx] = leaf;
         }
@@ -203,8 +240,8 @@ __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
 
 PDA_EXPORT void pda_dqn_head(const DqnHeadArgs* args, hipStream_t stream) {
     DqnHeadArgs p = *args;
-    const int wpb = p.B <= 1024 ? 1 : 4;
-    dim3 grid((p.B + wpb - 1) / wpb), block(64 * wpb);
+    if (p.A > 32 || p.dq_ld > 256) return;      // (lane-per-action layout; the python side checks the same)
+    dim3 grid(p.B), block(256);
     if (p.HID == 512) hipLaunchKernelGGL(dqn_head_kernel<512>, grid, block, 0, stream, p);
     else if (p.HID == 256) hipLaunchKernelGGL(dqn_head_kernel<256>, grid, block, 0, stream, p);
 }

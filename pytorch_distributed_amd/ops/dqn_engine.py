@@ -764,6 +764,10 @@ class DqnStepProgram(object):
         # workgroups' HBM streams slow the GEMM workgroups' operand loads by more than the overlap returns, and the
         # conv head then needs a launch of its own -- so it stays off.
         self.pair_adam = self.fused_tail and os.environ.get("PDA_PAIR_ADAM", "0") == "1"
+        # (Measured and removed in round 3: the fc tail's optimizer update on a side stream, forked after the fc
+        # weight gradients and joined at the end of the step, i.e. under the conv backward: 9.1k vs 10.6k updates/s
+        # fp32-class, 11.1k vs 13.5k bf16.  Like the forked weight gradients before it: a cross-stream edge inside
+        # the step graph costs more than the overlapped work returns at these kernel sizes.)
         if self.dp:
             e = engine
             e.adam.set_grad_scale(1.0 / self.world)
