@@ -283,7 +283,7 @@ def _host_inference(args, core, model, mailbox, device, slot_range=None):
 
 
 class _LoopProfile(object):
-    """PDA_LEARNER_PROF=1: where the learner loop's wall time goes inside the whole job -- host time in drain() /
+    """Knob learner_prof (PDA_LEARNER_PROF=1): where the learner loop's wall time goes inside the whole job -- host time in drain() /
     core.step() / the rest of an iteration, and how often the GPU had ALREADY run dry when the next step was handed
     to it (host-bound) -- written to <log_dir>/learner_loop_profile.json at the end.  Off by default: the stream
     query costs a few microseconds per iteration."""
@@ -457,14 +457,16 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
     world = args.num_learners
     if args.device == "cuda":
         ngpu = torch.cuda.device_count()        # (does not initialise the GPU)
-        if world > 1 and getattr(args, "compute", "auto") != "torch" and "PDA_DP_GRAPH" not in os.environ:
+        from ..ops.knobs import resolve as resolve_knobs
+        if world > 1 and getattr(args, "compute", "auto") != "torch" and resolve_knobs(args).dp_graph == "auto":
             # may the step graph contain the process group's collectives on this node?  Asked of a throw-away child
             # BEFORE this process touches the GPU (parallel/preflight.py); only matters when the peer kernel is out
             from ..parallel.preflight import choose_dp_graph_mode
             os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
                                "LOCAL_RANK": str((args.gpu_ind + rank) % max(ngpu, 1)),
                                "MASTER_PORT": str(int(getattr(args, "dist_port", 29533)) + 101)})
-            os.environ["PDA_DP_GRAPH"] = choose_dp_graph_mode(port_offset=0)
+            args.engine_knobs = dict(getattr(args, "engine_knobs", None) or {},
+                                     dp_graph=choose_dp_graph_mode(port_offset=0))
         local_device = torch.device("cuda:%d" % ((args.gpu_ind + rank) % max(ngpu, 1)))
         torch.cuda.set_device(local_device)
         # a GPU learner's host work is launches and small copies: no intra-op thread pool (its workers keep spinning
@@ -557,7 +559,8 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
     global_logs.beat("learner", process_ind)
     last_beat = time.time()
     from .actors import _maybe_fault
-    prof = _LoopProfile(local_device) if os.environ.get("PDA_LEARNER_PROF", "0") == "1" else None
+    from ..ops.knobs import resolve as _resolve_knobs
+    prof = _LoopProfile(local_device) if _resolve_knobs(args).learner_prof else None
     while step < ap.steps:
         if prof is not None and started:
             prof.begin()

@@ -40,6 +40,7 @@ PDA_EXPORT void pda_conv1_fwd_u8_x3(const void* const* frames, const void* const
                                     long w_plane, const void* const* bias, void* const* out, long out_plane,
                                     int ngroups, int batch, int H, int W, int C, float scale, int act,
                                     hipStream_t stream);
+PDA_EXPORT int pda_generic_conv1_forced();
 PDA_EXPORT int pda_cnn_fwd_stack_supported(int H, int W, int C);
 PDA_EXPORT void pda_cnn_fwd_stack(const void* const* frames, const void* const* idx, const void* const* w1,
                                   const void* const* b1, const void* const* w2, const void* const* b2,

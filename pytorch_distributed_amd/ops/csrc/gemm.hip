@@ -12,11 +12,17 @@ namespace {
 // fewer 64x64 tiles than CUs on the chip: halve the tile so that twice the workgroups share the work
 bool small_grid(int M, int N, int groups) {
     long tiles = (long)((M + 63) / 64) * ((N + 63) / 64) * groups;
-    static const bool off = [] { const char* e = getenv("PDA_NO_SMALL_TILES"); return e && e[0] == '1'; }();
-    return !off && tiles < 224;
+    return tiles < 224;
 }
 
+int g_force_generic_conv1 = 0;
+
 }  // namespace
+
+// test hook (tests/test_gpu_gemm.py, ops/nn.py:force_generic_conv1): run the Nature conv1 geometry through the generic
+// implicit-GEMM loaders instead of the whole-image kernels
+PDA_EXPORT void pda_force_generic_conv1(int on) { g_force_generic_conv1 = on; }
+PDA_EXPORT int pda_generic_conv1_forced() { return g_force_generic_conv1; }
 
 // ---- conv1 forward: uint8 planar frames (optionally gathered through idx) ----------
 // out[g][(b,oy,ox)][o] = act(scale * sum_k u8 * W[o][k] + bias[o]),  k = (c,ky,kx)
@@ -24,9 +30,8 @@ PDA_EXPORT void pda_conv_fwd_u8(const void* const* frames, const void* const* id
                                 const void* const* bias, void* const* out, int ngroups, int batch,
                                 int H, int W, int C, int KH, int KW, int S, int O, float scale, int act,
                                 hipStream_t stream) {
-    // Nature conv1 geometry: the whole-image kernel (conv1_kernels.hip); PDA_CONV1_GENERIC=1 keeps this loader
-    const char* env = getenv("PDA_CONV1_GENERIC");
-    const bool generic_only = env && env[0] == '1';
+    // Nature conv1 geometry: the whole-image kernel (conv1_kernels.hip), unless the test hook keeps this loader
+    const bool generic_only = g_force_generic_conv1 != 0;
     if (!generic_only && ngroups <= GEMM_MAX_GROUPS && pda_conv1_supported(H, W, C, KH, KW, S, O)) {
         pda_conv1_fwd_u8(frames, idx, w, bias, out, ngroups, batch, H, W, C, scale, act, stream);
         return;
@@ -239,9 +244,8 @@ PDA_EXPORT void pda_fc_backward_duo(const void* d_dy, const void* d_w, const voi
         maxN = wKin[i] > maxN ? wKin[i] : maxN;
     }
     int3 g2 = plan_gemm<64, 64>(a2, 2, maxM, maxN, B, 0);
-    // measured at batch 128: 12.55k vs 12.40k updates/s for the plain order (PDA_XCD_ORDER=0)
-    static const bool want_xcd = std::getenv("PDA_XCD_ORDER") == nullptr || std::atoi(std::getenv("PDA_XCD_ORDER")) != 0;
-    const int xcd = want_xcd && g1.y == 1 && g2.y == 1;
+    // XCD-aware tile order: measured at batch 128, 12.55k vs 12.40k updates/s for the plain order
+    const int xcd = g1.y == 1 && g2.y == 1;
     int blocks = xcd ? xcd_cols_blocks(g1, a1.tiles_n) + xcd_cols_blocks(g2, a2.tiles_n)
                      : g1.x * g1.y * g1.z + g2.x * g2.y * g2.z;
     hipLaunchKernelGGL((gemm_duo_kernel<32, 64, 1, 4, SrcDenseK, SrcDenseT, EpiMaskBf16,
@@ -285,66 +289,10 @@ PDA_EXPORT void pda_conv_wgrad_pair(const void* const* dy, const void* const* x,
         if (K > maxN) maxN = K;
         if (M > maxK) maxK = M;
     }
-    static const bool xcd = std::getenv("PDA_XCD_ORDER") == nullptr || std::atoi(std::getenv("PDA_XCD_ORDER")) != 0;
-    if (!xcd) { launch_gemm<64, 64, 2, 2>(a, 2, O, maxN, maxK, ksplit, stream); return; }
     int3 grid = plan_gemm<64, 64>(a, 2, O, maxN, maxK, ksplit);
     int units = grid.y * grid.z;
     hipLaunchKernelGGL((gemm_xcd_kernel<64, 64, 2, 2, GEMM_BK, SrcDenseT, SrcIm2colT, EpiWgrad>),
                        dim3((units + 7) / 8 * 8 * grid.x), dim3(GEMM_THREADS), 0, stream, a, grid);
-}
-
-// The conv2 / conv3 weight-gradient pair and the optimizer update of the fc tail in ONE launch.  At batch 128 the
-// fc gradients are final before the conv ones are (the fc backward runs first), and 95 % of the parameters are
-// fc1's: their Adam workgroups stream HBM while the GEMM workgroups of the pair sit in MFMA / LDS latency, instead
-// of the two launches running back to back (10.8 + 13.9 us).  The conv head of the optimizer follows as a short
-// launch of its own (rl_kernels.hip: pda_adam_x with the head table).
-// Measured: the step gets SLOWER (85.0 vs 79.9 us) -- the co-resident Adam streams delay the GEMM workgroups' operand
-// loads -- so the engine only takes this path on request (PDA_PAIR_ADAM=1, ops/dqn_engine.py).
-struct AdamLaunch {
-    float *p, *g, *m, *v; bf16_t* shadow; const SegEntry* segs; const int2* chunks; int nchunks;
-    const float* hyper; const int* step;
-};
-__global__ __launch_bounds__(GEMM_THREADS) void adam_wgrad_pair_kernel(GemmArgs<SrcDenseT, SrcIm2colT, EpiWgrad> wg,
-                                                                       int3 grid, AdamLaunch A) {
-    constexpr int LG = gemm_lds_elems<64, 64, GEMM_BK, SrcDenseT, SrcIm2colT>() * (int)sizeof(bf16_t);
-    constexpr int LA = OPT_ROW_LDS * (int)sizeof(float);
-    __shared__ __attribute__((aligned(16))) char lds[LG > LA ? LG : LA];
-    int b = blockIdx.x;
-    const int ng = grid.x * grid.y * grid.z;
-    if (b < ng) {       // the GEMM workgroups first: they are the longer ones
-        gemm_body<64, 64, 2, 2, GEMM_BK, SrcDenseT, SrcIm2colT, EpiWgrad>(wg, b % grid.x, (b / grid.x) % grid.y,
-                                                                           b / (grid.x * grid.y),
-                                                                           reinterpret_cast<bf16_t*>(lds));
-    } else {
-        AdamExtras x = {};
-        adam_block(A.p, A.g, A.m, A.v, A.shadow, A.segs, A.chunks, A.nchunks, A.hyper, A.step, x, b - ng,
-                   reinterpret_cast<float*>(lds));
-    }
-}
-PDA_EXPORT void pda_adam_with_wgrad_pair(const void* const* dy, const void* const* x, void* const* gw, void* const* gb,
-                                         int batch, const int* H, const int* W, const int* C, const int* KH,
-                                         const int* KW, const int* S, int O, const long* slice_stride,
-                                         const long* bslice_stride, int ksplit,
-                                         void* p, void* g, void* m, void* v, void* shadow, const void* segs,
-                                         const void* chunks, int nchunks, const void* hyper, void* step,
-                                         hipStream_t stream) {
-    GemmArgs<SrcDenseT, SrcIm2colT, EpiWgrad> a;
-    int maxN = 0, maxK = 0;
-    for (int i = 0; i < 2; ++i) {
-        ConvGeom geo = make_geom(H[i], W[i], C[i], KH[i], KW[i], S[i]);
-        int M = batch * geo.OH * geo.OW, K = C[i] * KH[i] * KW[i];
-        a.g[i].a = {(const bf16_t*)dy[i], (long)O, O, M};
-        a.g[i].b = {(const bf16_t*)x[i], geo, K, M};
-        a.g[i].e = {(float*)gw[i], (float*)gb[i], (long)K, slice_stride[i], bslice_stride[i], 1.f};
-        a.g[i].M = O; a.g[i].N = K; a.g[i].K = M;
-        if (K > maxN) maxN = K;
-        if (M > maxK) maxK = M;
-    }
-    int3 grid = plan_gemm<64, 64>(a, 2, O, maxN, maxK, ksplit);
-    AdamLaunch A = {(float*)p, (float*)g, (float*)m, (float*)v, (bf16_t*)shadow, (const SegEntry*)segs,
-                    (const int2*)chunks, nchunks, (const float*)hyper, (const int*)step};
-    hipLaunchKernelGGL(adam_wgrad_pair_kernel, dim3(grid.x * grid.y * grid.z + nchunks), dim3(GEMM_THREADS), 0,
-                       stream, a, grid, A);
 }
 
 // conv1 from uint8 frames: gw[O][(c,ky,kx)] (== PyTorch's own order)

@@ -31,7 +31,7 @@ PDA_EXPORT void pda_x3_conv_fwd_u8(const void* const* frames, const void* const*
                                    long w_plane, const void* const* bias, void* const* out, long out_plane,
                                    int ngroups, int batch, int H, int W, int C, int KH, int KW, int S, int O,
                                    float scale, int act, hipStream_t stream) {
-    static const bool generic_only = std::getenv("PDA_X3_CONV1_GENERIC") != nullptr;
+    const bool generic_only = pda_generic_conv1_forced() != 0;
     if (!generic_only && ngroups <= GEMM_MAX_GROUPS && pda_conv1_supported(H, W, C, KH, KW, S, O)) {
         // whole-image kernel: the frame stack is read once into LDS, both weight planes live in registers
         pda_conv1_fwd_u8_x3(frames, idx, w, w_plane, bias, out, out_plane, ngroups, batch, H, W, C, scale, act, stream);

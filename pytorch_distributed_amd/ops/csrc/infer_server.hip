@@ -111,8 +111,7 @@ void enqueue_program(Server& S, int n) {
         void* o1[1] = {S.a1}; void* o2[1] = {S.a2}; void* o3[1] = {S.a3};
         const void* x1[1] = {S.a1}; const void* x2[1] = {S.a2}; const void* x3[1] = {S.a3};
         void* o32[1] = {S.h1pre};
-        const char* nofuse = getenv("PDA_FUSED_FWD");
-        if (pda_cnn_fwd_stack_supported(c.H, c.W, c.C) && !(nofuse && nofuse[0] == '0')) {
+        if (pda_cnn_fwd_stack_supported(c.H, c.W, c.C)) {
             // the three conv layers in one launch, intermediates in LDS (conv1_kernels.hip)
             void* none[1] = {nullptr};
             pda_cnn_fwd_stack(frames, idx, w0, b0, w1, b1, w2, b2, none, none, o3, 1, n, c.H, c.W, c.C, c.inv_norm, st);

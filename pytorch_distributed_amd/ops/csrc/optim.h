@@ -122,8 +122,7 @@ __device__ __forceinline__ float grad_at(const AdamExtras& x, int seg, int e, fl
 }
 
 // One workgroup (256 threads) of the optimizer launch: chunk `bid` of the table, or a sampler block past
-// it.  `row` = OPT_ROW_LDS floats of LDS.  A device function so that other launches can carry optimizer
-// workgroups next to their own (gemm.hip: adam_wgrad_pair_kernel).
+// it.  `row` = OPT_ROW_LDS floats of LDS.
 __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restrict__ g,
                                            float* __restrict__ m, float* __restrict__ v,
                                            bf16_t* __restrict__ shadow, const SegEntry* __restrict__ segs,

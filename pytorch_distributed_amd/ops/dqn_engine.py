@@ -32,6 +32,7 @@ import numpy as np
 import torch
 
 from . import lib, nn
+from .knobs import resolve as resolve_knobs
 from .optim import AdamExtras, FlatAdam, SegmentTable, polyak_
 
 _vp = ctypes.c_void_p
@@ -90,9 +91,9 @@ def _L():
 
 
 class _Range(object):
-    """roctx range around a learner phase when PDA_ROCTX=1 (visible in rocprofv3 --marker-trace of an
+    """roctx range around a learner phase when the `roctx` knob is set (visible in rocprofv3 --marker-trace of an
     eager, non-graph run); a no-op otherwise."""
-    enabled = bool(int(os.environ.get("PDA_ROCTX", "0") or 0))
+    enabled = False     # set by DqnStepProgram from its knobs
 
     def __init__(self, name):
         self.name = name
@@ -249,6 +250,7 @@ class _Acts(object):
         self.a3 = [z(B * g.P3, 64) for _ in range(groups)]
         self.h1pre = [z(B, g.HID, dtype=torch.float32) for _ in range(groups)]
         self.h1_slices, self.h1_ksplit = 0, 0       # > 0: fc1's split-K sums arrive as slabs (fc1_slabs below)
+        self.fc1_blocks = 256                       # split-K target of fc1's forward (knobs.fc1_blocks)
         if backward:
             self.h1 = z(B, g.HID)
             self.dh1 = z(B, g.HID)
@@ -258,26 +260,14 @@ class _Acts(object):
             self.da2 = z(B * g.H2 * g.W2, 64)
             self.da1 = z(B * g.H1 * g.W1, 32)
             self.stack_dgrad = nn.cnn_dgrad_stack_supported(g.H, g.W, g.C) and not self.split
-            # gather-form data gradients need no dcol matrices; odd layer geometries fall back to
-            # dcol GEMM + col2im
-            # (measured on MI355X: the gather form is ~4 % slower end to end at batch 128 and 4096 --
-            # 4-9 latency-bound k-tiles against one output-bound tile + a bandwidth pass -- so it is
-            # opt-in; it saves the dcol buffers: 0.9 GB at batch 4096)
-            self.fused_dgrad = g.H1 % 2 == 0 and g.W1 % 2 == 0 and (os.environ.get("PDA_FUSED_DGRAD", "0") == "1"
-                                                                    or self.split)
-            if self.split and not self.fused_dgrad:
+            # bf16 engine, geometries the per-image stack does not cover: dcol GEMM + col2im.  (The gather form
+            # was ~4 % slower end to end at batch 128 and 4096 on the bf16 engine and is gone from it; the
+            # fp32-class engine has only the gather form, which needs even conv1 output sides.)
+            if self.split and (g.H1 % 2 or g.W1 % 2):
                 raise ValueError("the fp32-precision engine needs even conv1 output sides (gather-form dgrad)")
-            if not self.fused_dgrad and not self.stack_dgrad:
+            if not self.split and not self.stack_dgrad:
                 self.dcol3 = z(B * g.P3, g.K3)
                 self.dcol2 = z(B * g.H2 * g.W2, g.K2)
-
-
-_WGRAD_BLOCKS = int(os.environ.get("PDA_WGRAD_BLOCKS", "256"))  # split-K target for the conv weight gradients
-# batch from which the per-image conv2+conv3 wgrad kernel is used: at 4096 it is worth +5.8 % (1224 -> 1295 updates/s;
-# the kernel itself 197 -> 101 us, but the optimizer then sums 256 slab slices); at 1024 it loses (3528 -> 3247)
-_WGRAD_STACK_MIN = int(os.environ.get("PDA_WGRAD_STACK_MIN", "4096"))
-_PAIR_BLOCKS = int(os.environ.get("PDA_PAIR_BLOCKS", "512"))    # same, for the conv2 + conv3 launch as a whole
-_FC1_BLOCKS = int(os.environ.get("PDA_FC1_BLOCKS", "256"))     # split-K target for fc1 forward (blocks per launch)
 
 
 def cnn_forward(geom, nets, frames, idxs, acts, B, norm_val, keep_first_only=True):
@@ -307,7 +297,7 @@ def cnn_forward(geom, nets, frames, idxs, acts, B, norm_val, keep_first_only=Tru
             return
         tiles = ((B + 63) // 64) * (g.HID // 64) * n
         nn.x3_linear_fwd(acts.a3[:n], [w.w[3] for w in nets], acts.h1pre[:n], B, g.HID, g.F, g.F, g.F, g.HID,
-                         ksplit=_ksplit(g.F, tiles, _FC1_BLOCKS, 128))
+                         ksplit=_ksplit(g.F, tiles, acts.fc1_blocks, 128))
         return
     if nn.cnn_fwd_stack_supported(g.H, g.W, g.C):
         # one launch, one workgroup per image; only group 0 (the trained network on s0) keeps a1 / a2
@@ -328,7 +318,7 @@ def cnn_forward(geom, nets, frames, idxs, acts, B, norm_val, keep_first_only=Tru
         return
     tiles = ((B + 63) // 64) * (g.HID // 64) * n
     nn.linear_fwd(acts.a3[:n], [w.w[3] for w in nets], None, None, acts.h1pre[:n], B, g.HID, g.F, g.F, g.F,
-                  0, g.HID, ksplit=_ksplit(g.F, tiles, _FC1_BLOCKS, 128))
+                  0, g.HID, ksplit=_ksplit(g.F, tiles, acts.fc1_blocks, 128))
 
 
 def fc1_slabs(acts, geom, B, groups, device):
@@ -337,7 +327,7 @@ def fc1_slabs(acts, geom, B, groups, device):
     g = geom
     mult = 1        # (split operands: the x3 GEMM body reduces over the logical K, csrc/gemm.h gemm_body_x3)
     tiles = ((B + 63) // 64) * (g.HID // 64) * groups
-    ks = _ksplit(mult * g.F, tiles, _FC1_BLOCKS, 128)
+    ks = _ksplit(mult * g.F, tiles, acts.fc1_blocks, 128)
     acts.h1_ksplit = ks
     acts.h1_slices = nn.num_slices(mult * g.F, ks)
     acts.h1pre = [torch.zeros(acts.h1_slices, B, g.HID, dtype=torch.float32, device=device) for _ in range(groups)]
@@ -347,14 +337,17 @@ class DqnCnnEngine(object):
     """One learner's device state and step program."""
 
     def __init__(self, model, target_model, batch_size, lr=1e-4, weight_decay=0.0, clip=np.inf,
-                 double=False, target_update=250, per=None, seed=0, tail_offsets=(0, 1, 2, 3), precision="bf16"):
-        """precision: "bf16" = bf16 MFMA operands (per-image fused conv kernels); "fp32" = every product a
+                 double=False, target_update=250, per=None, seed=0, tail_offsets=(0, 1, 2, 3), precision="bf16",
+                 knobs=None):
+        """knobs: ops.knobs.Knobs (split-K targets etc.; None = resolved from defaults / environment here).
+        precision: "bf16" = bf16 MFMA operands (per-image fused conv kernels); "fp32" = every product a
         split-bf16 x3 product with fp32 accumulation (csrc/gemm_x3.hip), the reference learner's precision."""
         self.geom = g = CnnGeometry(model.input_dims, model.output_dims, model.critic[1][0].out_features)
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32', not %r" % (precision,))
         self.precision = precision
         self.x3 = x3 = precision == "fp32"
+        self.knobs = knobs if knobs is not None else resolve_knobs()
         self.B = int(batch_size)
         self.norm_val = float(model.norm_val)
         self.double = bool(double)
@@ -370,22 +363,21 @@ class DqnCnnEngine(object):
                              clip=clip, shadow=self.online.shadow, shadow_plane=self.online.shadow_plane)
         self.groups = 3 if self.double else 2
         self.acts = _Acts(g, self.B, self.groups, dev, backward=True, split=x3)
+        self.acts.fc1_blocks = self.knobs.fc1_blocks
         # fc1 forward split-K as slabs summed by the head kernel: makes two runs of a step program bit-identical
         # (the last source of run-to-run differences was the arrival order of fc1's fp32 atomics)
-        if os.environ.get("PDA_FC1_SLAB", "1") != "0":
-            fc1_slabs(self.acts, g, self.B, self.groups, dev)
-        self.deterministic = self.acts.h1_slices > 0
-        self.pair_wgrad = (bool(self.acts.stack_dgrad) or x3) and os.environ.get("PDA_PAIR_WGRAD", "1") != "0"
+        fc1_slabs(self.acts, g, self.B, self.groups, dev)
+        self.deterministic = True
+        # conv2 + conv3 weight gradients as two problem groups of ONE launch
+        self.pair_wgrad = bool(self.acts.stack_dgrad) or x3
         # large batches: conv2 + conv3 weight gradients per image with register accumulation (csrc/conv1_kernels.hip)
-        self.stack_wgrad = bool(self.acts.stack_dgrad) and self.B >= _WGRAD_STACK_MIN and not x3
+        self.stack_wgrad = bool(self.acts.stack_dgrad) and self.B >= self.knobs.wgrad_stack_min and not x3
         # fc1's data gradient in the launch of the two fc weight gradients (small batches: all three under-fill the GPU)
-        self.fc_duo = self.B <= 512 and not self.overlap_wgrad_env() and os.environ.get("PDA_FC_DUO", "1") != "0"
+        self.fc_duo = self.B <= 512
         # conv1's weight gradient as a tail of the dgrad stack launch (da1 still in LDS)
-        self.fuse_w1 = (bool(self.acts.stack_dgrad) and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32)
-                        and os.environ.get("PDA_FUSE_W1", "1") != "0" and not x3)
+        self.fuse_w1 = bool(self.acts.stack_dgrad) and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32) and not x3
         # the same for the fp32-precision dgrad stack (two workgroups = two slab slices per image: small batches)
-        self.x3_fuse_w1 = (x3 and nn.x3_cnn_dgrad_stack_supported(g.H, g.W, g.C) and self.B <= 256
-                           and os.environ.get("PDA_FUSE_W1", "1") != "0")
+        self.x3_fuse_w1 = x3 and nn.x3_cnn_dgrad_stack_supported(g.H, g.W, g.C) and self.B <= 256
         self._plan_wgrads()
         self._fc_pair = None
         self.idx = torch.zeros(self.B, dtype=torch.int32, device=dev)
@@ -403,13 +395,10 @@ class DqnCnnEngine(object):
         self.step_count = 0
         # the tail bucket [fc1.weight .. end] is ready right after the two fc wgrads
         self.tail_start = self.online.off["critic.1.0"][0]
-        # weight gradients run on a side stream beside the data-gradient chain (a forked branch of the
-        # step's hipGraph): at batch 128 every kernel fills a fraction of the chip, so the branch is free
-        self.side = torch.cuda.Stream(device=dev)
-        self.ev_fork, self.ev_da3, self.ev_da2, self.ev_side = (torch.cuda.Event() for _ in range(4))
-        # (measured: 4828 vs 5240 updates/s -- cross-stream edges inside a hipGraph cost more than the
-        # overlap returns on this runtime, so the branch is off unless asked for)
-        self.overlap_wgrad = os.environ.get("PDA_OVERLAP_WGRAD", "0") == "1"
+        # (Single rank: every kernel of the step runs on ONE stream.  Forking the weight gradients -- or the fc tail's
+        # optimizer update -- onto a side stream as a branch of the step's hipGraph was measured slower three times
+        # (4828 vs 5240, 9.1k vs 10.6k, 11.1k vs 13.5k updates/s): a cross-stream edge inside a graph costs more
+        # than the overlapped work returns at these kernel sizes.  Those paths are gone.)
         self._target_copy(1.0)      # hard copy to start
 
     def _target_copy(self, tau):
@@ -426,14 +415,14 @@ class DqnCnnEngine(object):
                                           (64, g.K3, mult[2] * B * g.P3)]):
             tiles = ((O + 63) // 64 if O > 32 else 1) * ((K + 63) // 64)
             # (fp32 precision: the reductions are 2-3 x longer; more, shorter slices measured 3.51k -> 3.77k updates/s)
-            wg_blocks = _WGRAD_BLOCKS * (int(os.environ.get("PDA_X3_WGRAD_MULT", 2)) if self.x3 else 1)
-            pair_blocks = _PAIR_BLOCKS * (int(os.environ.get("PDA_X3_PAIR_MULT", 1)) if self.x3 else 1)
+            wg_blocks = self.knobs.wgrad_blocks * (self.knobs.x3_wgrad_mult if self.x3 else 1)
+            pair_blocks = self.knobs.pair_blocks * (self.knobs.x3_pair_mult if self.x3 else 1)
             ks = _ksplit(red, tiles, wg_blocks, 128)
             if li > 0 and self.stack_wgrad:
                 ks, ns_override = 0, nn.cnn_wgrad_stack_slices(B)      # per-image kernel: one slice per workgroup
             elif li > 0 and self.pair_wgrad:
                 # conv2 + conv3 go out as two problem groups of one launch with a common slice length, sized so
-                # that the launch as a whole is ~_PAIR_BLOCKS workgroups
+                # that the launch as a whole is ~knobs.pair_blocks workgroups
                 work = mult[1] * (8 * (B * g.H2 * g.W2) + 9 * (B * g.P3))
                 ks = nn.round_ksplit(max(128, (work + pair_blocks - 1) // pair_blocks))
             ns = nn.num_slices(red, ks) if ks > 0 else ns_override
@@ -525,10 +514,6 @@ class DqnCnnEngine(object):
             h1_slices=a.h1_slices, h1_slice_stride=B * g.HID)
         _L().pda_dqn_head(ctypes.byref(args), _stream())
 
-    @staticmethod
-    def overlap_wgrad_env():
-        return os.environ.get("PDA_OVERLAP_WGRAD", "0") == "1"
-
     def backward_fc(self):
         g, B, a = self.geom, self.B, self.acts
         # one slice each, written straight into the gradient buffer (kernel layout); both in one launch
@@ -558,25 +543,14 @@ class DqnCnnEngine(object):
     def presamples(self, staged):
         return (not staged) and self.replay is not None and not (self.replay[3] is not None and self.per is not None)
 
-    def backward_conv(self, staged=False, reduce=True, adam_tail=None):
-        """adam_tail: a SegmentTable of segments whose gradients are final already (the fc tail); their optimizer
-        update then rides in the conv2/conv3 weight-gradient launch.  Returns True when it did."""
+    def backward_conv(self, staged=False, reduce=True):
+        """reduce: sum the split-K slabs with a launch of their own (data parallel: the all-reduce needs the sums);
+        False when the optimizer launch sums them (fused_extras)."""
         g, B, a = self.geom, self.B, self.acts
-        tail_done = False
         s0, _, _, idx, _ = self._sources(staged)
         on = self.online
         M3, M2 = B * g.P3, B * g.H2 * g.W2
         (w1s, b1s, ks1, st1, bst1), (w2s, b2s, ks2, st2, bst2), (w3s, b3s, ks3, st3, bst3) = self.wg_slabs
-        cur, side, fork = torch.cuda.current_stream(), self.side, self.overlap_wgrad
-
-        def on_side(ready, fn):
-            """fn() on the side stream once `ready` (recorded here on the main stream) has passed."""
-            if not fork:
-                return fn()
-            ready.record(cur)
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
-                fn()
 
         if self.x3:
             # fp32 precision: gather-form data gradients and split-K weight gradients on split-bf16 planes
@@ -592,18 +566,13 @@ class DqnCnnEngine(object):
                 nn.x3_conv_dgrad(a.da2, on.w[1], a.a1[0].hi, a.da1, B, g.H1, g.W1, 32, 4, 4, 2, 64, act=nn.ACT_RELU)
             geoms = [(g.H1, g.W1, 32, 4, 4, 2), (g.H2, g.W2, 64, 3, 3, 1)]
 
-            def conv1_wgrad():
-                if self.x3_fuse_w1:
-                    return          # done by the dgrad stack launch
-                if nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32):
-                    nn.x3_conv1_wgrad_u8_whole(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 1.0 / self.norm_val, st1,
-                                               bst1)
-                else:
-                    nn.x3_conv_wgrad_u8(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / self.norm_val,
-                                        ksplit=ks1, slice_stride=st1, bslice_stride=bst1)
-            # conv1's weight gradient (one workgroup per CU, LDS-bound occupancy) beside the conv2 / conv3 pair
-            # (PDA_OVERLAP_WGRAD=1: a forked branch of the step's graph)
-            on_side(self.ev_da2, conv1_wgrad)
+            if self.x3_fuse_w1:
+                pass                # conv1's weight gradient was computed by the dgrad stack launch
+            elif nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32):
+                nn.x3_conv1_wgrad_u8_whole(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 1.0 / self.norm_val, st1, bst1)
+            else:
+                nn.x3_conv_wgrad_u8(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / self.norm_val,
+                                    ksplit=ks1, slice_stride=st1, bslice_stride=bst1)
             if self.pair_wgrad:
                 assert ks2 == ks3
                 nn.x3_conv_wgrad([a.da2, a.da3], [a.a1[0], a.a2[0]], [w2s, w3s], [b2s, b3s], B, geoms, 64, ks2,
@@ -611,12 +580,9 @@ class DqnCnnEngine(object):
             else:
                 nn.x3_conv_wgrad([a.da3], [a.a2[0]], [w3s], [b3s], B, geoms[1:], 64, ks3, [st3], [bst3])
                 nn.x3_conv_wgrad([a.da2], [a.a1[0]], [w2s], [b2s], B, geoms[:1], 64, ks2, [st2], [bst2])
-            if fork:
-                self.ev_side.record(side)
-                cur.wait_event(self.ev_side)
             if reduce:
                 self.reduce.run()
-            return False
+            return
         if not self.fc_duo:
             nn.linear_dgrad(a.dh1, on.w[3], a.a3[0], a.da3, B, g.HID, g.F, g.HID, g.F, g.F, g.F, act=nn.ACT_RELU)
         if a.stack_dgrad:
@@ -629,47 +595,33 @@ class DqnCnnEngine(object):
                 assert ks2 == ks3
                 pair = ([a.da2, a.da3], [a.a1[0], a.a2[0]], [w2s, w3s], [b2s, b3s], B,
                         [(g.H1, g.W1, 32, 4, 4, 2), (g.H2, g.W2, 64, 3, 3, 1)], 64, ks2, [st2, st3], [bst2, bst3])
-                if adam_tail is not None:
-                    nn.adam_with_wgrad_pair(*pair, self.adam, adam_tail)
-                    tail_done = True
-                else:
-                    nn.conv_wgrad_pair(*pair)
+                nn.conv_wgrad_pair(*pair)
             else:
                 nn.conv_wgrad(a.da3, a.a2[0], w3s, b3s, B, g.H2, g.W2, 64, 3, 3, 1, 64, ksplit=ks3, slice_stride=st3,
                               bslice_stride=bst3)
                 nn.conv_wgrad(a.da2, a.a1[0], w2s, b2s, B, g.H1, g.W1, 32, 4, 4, 2, 64, ksplit=ks2, slice_stride=st2,
                               bslice_stride=bst2)
         else:
-            self._backward_conv_layerwise(a, on, B, M3, M2, on_side, (w3s, b3s, ks3, st3, bst3),
-                                          (w2s, b2s, ks2, st2, bst2))
+            self._backward_conv_layerwise(a, on, B, M3, M2, (w3s, b3s, ks3, st3, bst3), (w2s, b2s, ks2, st2, bst2))
         if not (a.stack_dgrad and self.fuse_w1):
             nn.conv_wgrad_u8(a.da1, s0, idx, w1s, b1s, B, g.H, g.W, g.C, 8, 8, 4, 32, 1.0 / self.norm_val,
                              ksplit=ks1, slice_stride=st1, bslice_stride=bst1)
-        if fork:                # join: everything queued on the side stream (incl. fc wgrads put there by the caller)
-            self.ev_side.record(side)
-            cur.wait_event(self.ev_side)
         if reduce:
             self.reduce.run()
-        return tail_done
 
-    def _backward_conv_layerwise(self, a, on, B, M3, M2, on_side, s3, s2):
-        """conv3 / conv2 weight and data gradients as separate launches (generic geometries; PDA_FUSED_BWD=0)."""
+    def _backward_conv_layerwise(self, a, on, B, M3, M2, s3, s2):
+        """bf16 engine, generic geometries: conv3 / conv2 weight and data gradients as separate launches (data
+        gradient = dcol GEMM + col2im)."""
         g = self.geom
         (w3s, b3s, ks3, st3, bst3), (w2s, b2s, ks2, st2, bst2) = s3, s2
-        on_side(self.ev_da3, lambda: nn.conv_wgrad(a.da3, a.a2[0], w3s, b3s, B, g.H2, g.W2, 64, 3, 3, 1, 64,
-                                                   ksplit=ks3, slice_stride=st3, bslice_stride=bst3))
-        if a.fused_dgrad:
-            nn.conv_dgrad(a.da3, on.w[2], a.a2[0], a.da2, B, g.H2, g.W2, 64, 3, 3, 1, 64, act=nn.ACT_RELU)
-        else:
-            nn.linear_dgrad(a.da3, on.w[2], None, a.dcol3, M3, 64, g.K3, 64, g.K3, 0, g.K3)
-            nn.col2im(a.dcol3, a.a2[0], a.da2, B, g.H2, g.W2, 64, 3, 3, 1, act=nn.ACT_RELU)
-        on_side(self.ev_da2, lambda: nn.conv_wgrad(a.da2, a.a1[0], w2s, b2s, B, g.H1, g.W1, 32, 4, 4, 2, 64,
-                                                   ksplit=ks2, slice_stride=st2, bslice_stride=bst2))
-        if a.fused_dgrad:
-            nn.conv_dgrad(a.da2, on.w[1], a.a1[0], a.da1, B, g.H1, g.W1, 32, 4, 4, 2, 64, act=nn.ACT_RELU)
-        else:
-            nn.linear_dgrad(a.da2, on.w[1], None, a.dcol2, M2, 64, g.K2, 64, g.K2, 0, g.K2)
-            nn.col2im(a.dcol2, a.a1[0], a.da1, B, g.H1, g.W1, 32, 4, 4, 2, act=nn.ACT_RELU)
+        nn.conv_wgrad(a.da3, a.a2[0], w3s, b3s, B, g.H2, g.W2, 64, 3, 3, 1, 64, ksplit=ks3, slice_stride=st3,
+                      bslice_stride=bst3)
+        nn.linear_dgrad(a.da3, on.w[2], None, a.dcol3, M3, 64, g.K3, 64, g.K3, 0, g.K3)
+        nn.col2im(a.dcol3, a.a2[0], a.da2, B, g.H2, g.W2, 64, 3, 3, 1, act=nn.ACT_RELU)
+        nn.conv_wgrad(a.da2, a.a1[0], w2s, b2s, B, g.H1, g.W1, 32, 4, 4, 2, 64, ksplit=ks2, slice_stride=st2,
+                      bslice_stride=bst2)
+        nn.linear_dgrad(a.da2, on.w[1], None, a.dcol2, M2, 64, g.K2, 64, g.K2, 0, g.K2)
+        nn.col2im(a.dcol2, a.a1[0], a.da1, B, g.H1, g.W1, 32, 4, 4, 2, act=nn.ACT_RELU)
 
     def grads_torch_layout(self):
         """The flat gradient re-ordered to PyTorch's parameter layout (tests, debugging)."""
@@ -735,7 +687,9 @@ class DqnStepProgram(object):
         # updates, the next K - 1 calls return at once.  Only for the HBM-replay programs (single rank, or data
         # parallel with the collectives captured in the graph), and K is cut
         # down to a divisor of the hard target-update period so that those updates still fall between replays.
-        k = int(os.environ.get("PDA_GRAPH_STEPS", graph_steps) or 1)
+        self.knobs = knobs = engine.knobs
+        _Range.enabled = bool(knobs.roctx)
+        k = int(graph_steps or 1)
         if staged or not use_graph:
             k = 1
         tu = engine.target_update
@@ -748,26 +702,22 @@ class DqnStepProgram(object):
         # waits inside the runtime: the learner fell from 8.1 k to 4.9 k updates/s inside the job when its one
         # periodic host synchronisation (the loss read-out) was removed.  Three replays in flight keep the GPU fed
         # (a replay is ~0.5 ms of work, a launch ~20 us) and the queue short.
-        self.max_inflight = max(1, int(os.environ.get("PDA_MAX_INFLIGHT_REPLAYS", "3")))
+        self.max_inflight = max(1, int(knobs.max_inflight_replays))
         self._inflight = []
-        self.fused_tail = (not self.dp) and os.environ.get("PDA_FUSED_TAIL", "1") != "0"
+        # single rank: the split-K slab sums and the next step's index draw ride in the optimizer launch
+        self.fused_tail = not self.dp
         self.presampled = False
         self.extras = engine.fused_extras(staged) if self.fused_tail else None
         self.dp_extras = None
-        if self.dp and engine.presamples(staged) and os.environ.get("PDA_FUSED_TAIL", "1") != "0":
+        if self.dp and engine.presamples(staged):
             self.dp_extras = engine.fused_extras(staged, slabs=False)
         first_tail_seg = 2 * engine.online.ORDER.index("critic.1.0")     # (weight, bias) segment pairs per layer
         self.tail_table = engine.online.table.subset(lambda s: s >= first_tail_seg)
         self.head_table = engine.online.table.subset(lambda s: s < first_tail_seg)
-        # single rank, opt-in (PDA_PAIR_ADAM=1): the fc tail's optimizer update shares the conv2/conv3 weight-gradient
-        # launch.  Measured at batch 128: 11.76k vs 12.51k updates/s for the one-launch optimizer -- the Adam
-        # workgroups' HBM streams slow the GEMM workgroups' operand loads by more than the overlap returns, and the
-        # conv head then needs a launch of its own -- so it stays off.
-        self.pair_adam = self.fused_tail and os.environ.get("PDA_PAIR_ADAM", "0") == "1"
-        # (Measured and removed in round 3: the fc tail's optimizer update on a side stream, forked after the fc
-        # weight gradients and joined at the end of the step, i.e. under the conv backward: 9.1k vs 10.6k updates/s
-        # fp32-class, 11.1k vs 13.5k bf16.  Like the forked weight gradients before it: a cross-stream edge inside
-        # the step graph costs more than the overlapped work returns at these kernel sizes.)
+        # (Measured and removed: the fc tail's optimizer update co-launched with the conv2/conv3 weight-gradient
+        # GEMM -- 11.76k vs 12.51k updates/s at batch 128, the Adam workgroups' HBM streams slow the GEMM's operand
+        # loads by more than the overlap returns -- and the same update forked onto a side stream under the conv
+        # backward: 9.1k vs 10.6k fp32-class, 11.1k vs 13.5k bf16.)
         if self.dp:
             e = engine
             e.adam.set_grad_scale(1.0 / self.world)
@@ -778,19 +728,20 @@ class DqnStepProgram(object):
             self.head = e.grads[:e.tail_start]
             # the fc tail is 95 % of the gradient bytes (6.4 MB fp32): optionally all-reduced as bf16 -- half the
             # bytes on the xGMI links, which at ~0.1 ms of compute per step is what bounds data-parallel scaling.
-            # (PDA_DP_GRAD_DTYPE=bf16 | fp32, default fp32: the two conversion launches cost ~20 us per step in the
+            # (knob dp_grad_dtype = bf16 | fp32, default fp32: the two conversion launches cost ~20 us per step in the
             # 1-rank rehearsal -- 9.2k vs 7.8k updates/s -- so it only pays where the all-reduce saves more than that.)
-            self.grad_dtype = os.environ.get("PDA_DP_GRAD_DTYPE", "fp32").lower()
+            self.grad_dtype = knobs.dp_grad_dtype
             # The all-reduce itself: the one-kernel xGMI peer all-reduce (parallel/peer_allreduce.py: every rank maps
             # every peer's hand-off region through hipIpc; two hops over all links, replayable inside the step graph)
             # when it passes its self-test on every rank, else the process group's (RCCL ring / gloo).
-            # PDA_DP_ALLREDUCE=auto|peer|rccl.
+            # knob dp_allreduce = auto | peer | rccl.
             from ..parallel.peer_allreduce import make_grad_allreduce
-            kind = os.environ.get("PDA_DP_ALLREDUCE", "auto")
+            kind = knobs.dp_allreduce
             if not hasattr(comm, "backend") or not self.tail.is_cuda:
                 kind = "rccl"           # FakeComm / CPU tensors: the communicator's own reduce
-            self.ar_tail = make_grad_allreduce(comm, self.tail, kind, wire=self.grad_dtype)
-            self.ar_head = make_grad_allreduce(comm, self.head, kind)
+            self.ar_tail = make_grad_allreduce(comm, self.tail, kind, wire=self.grad_dtype,
+                                               workgroups=knobs.peer_workgroups)
+            self.ar_head = make_grad_allreduce(comm, self.head, kind, workgroups=knobs.peer_workgroups)
             self.allreduce_kind = self.ar_tail.kind
             self.peer = self.allreduce_kind.startswith("peer")
             if getattr(comm, "backend", None) != "nccl" and not self.peer:
@@ -817,45 +768,18 @@ class DqnStepProgram(object):
 
     def _whole(self):
         e = self.e
-        if self.fused_tail and not e.overlap_wgrad:
-            # single rank: slab reduction and next-step index draw ride in the optimizer launch
-            if not self.staged and not (self.presampled and e.presamples(self.staged)):
-                with _Range("learner/sample"):
-                    e.sample()
-            with _Range("learner/forward+td_head"):
-                e.forward_head(self.staged)
-            with _Range("learner/backward_fc"):
-                e.backward_fc()
-            with _Range("learner/backward_conv"):
-                tail_done = e.backward_conv(self.staged, reduce=False,
-                                            adam_tail=self.tail_table if self.pair_adam else None)
-            with _Range("learner/adam+target+tree"):
-                if tail_done:
-                    e.adam.step(table=self.head_table, extras=self.extras)
-                    e.post_update(self.staged)
-                else:
-                    e.update(self.staged, extras=self.extras)
-            self.presampled = True
-            return
-        if not e.overlap_wgrad:
-            self._part_a()
-            self._part_b()
-            self._part_c()
-            return
-        # single rank: the two fc weight gradients also leave the critical path (the side stream is
-        # joined inside backward_conv, before the split-K reduce)
-        if not self.staged:
+        if not self.staged and not (self.presampled and e.presamples(self.staged)):
             with _Range("learner/sample"):
                 e.sample()
         with _Range("learner/forward+td_head"):
             e.forward_head(self.staged)
-        cur = torch.cuda.current_stream()
-        e.ev_fork.record(cur)
-        with torch.cuda.stream(e.side):
-            e.side.wait_event(e.ev_fork)
+        with _Range("learner/backward_fc"):
             e.backward_fc()
-        self._part_b()
-        self._part_c()
+        with _Range("learner/backward_conv"):
+            e.backward_conv(self.staged, reduce=False)
+        with _Range("learner/adam+target+tree"):
+            e.update(self.staged, extras=self.extras)      # + slab sums + the next step's index draw
+        self.presampled = True
 
     def _capture(self, fns):
         graphs = []
@@ -944,10 +868,10 @@ class DqnStepProgram(object):
         step: 4899 vs 3810 updates/s in the 1-rank RCCL rehearsal).  RCCL's intra-node
         collectives are plain kernels and capture like any other launch; host-driven back-ends
         (gloo) cannot be captured, and a refused capture poisons the process, so the choice is
-        made up front: PDA_DP_GRAPH=whole|split, or by back-end.  bench.py sets the variable from
+        made up front: knob dp_graph = whole | split (PDA_DP_GRAPH), or by back-end.  bench.py sets the variable from
         a pre-flight child process (parallel/preflight.py) that tries the capture first.
         Every rank takes the same decision (MIN over ranks)."""
-        mode = os.environ.get("PDA_DP_GRAPH", "auto")
+        mode = self.knobs.dp_graph
         if self.peer and mode != "split":
             mode = "whole"      # the peer all-reduce is a plain kernel launch: nothing host-driven is left in the step
         if mode == "auto":
@@ -1047,7 +971,7 @@ class DqnNativeCore(object):
                                    clip=ap.clip_grad, double=ap.enable_double,
                                    target_update=ap.target_model_update, per=per,
                                    seed=args.seed * 7919 + 104729 * rank + 13, tail_offsets=(0, a, a + k, a + 2 * k),
-                                   precision=getattr(args, "precision", "bf16"))
+                                   precision=getattr(args, "precision", "bf16"), knobs=resolve_knobs(args))
         self.on_device = hasattr(memory, "tails") and getattr(memory, "attached", False) and memory.tails.is_cuda
         if self.on_device:
             self.engine.bind_replay(memory.state0s, memory.state1s, memory.tails, memory.tree)

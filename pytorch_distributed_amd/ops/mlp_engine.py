@@ -324,12 +324,11 @@ class DdpgMlpEngine(_EngineBase):
                              shadow=on.shadow)
         polyak_(self.target.flat, on.flat, 1.0, self.target.table, self.target.shadow)
         # one launch for forward + head + data gradients, one for all weight gradients, one for Adam + Polyak +
-        # the next index draw (csrc/mlp_fused.hip); PDA_MLP_FUSED=0 keeps the layer-by-layer launches
-        self.fused = (os.environ.get("PDA_MLP_FUSED", "1") != "0"
-                      and bool(_L().pda_ddpg_fused_supported(self.D, self.H1, self.H2, self.A, self.C1, self.C2)))
+        # the next index draw (csrc/mlp_fused.hip); shapes it does not cover run the layer-by-layer launches
+        self.fused = bool(_L().pda_ddpg_fused_supported(self.D, self.H1, self.H2, self.A, self.C1, self.C2))
         self._wgrad_jobs = None
         if self.actor_l2 > 0 and not self.fused:
-            raise ValueError("actor_preact_l2 is implemented by the fused DDPG kernel only (PDA_MLP_FUSED=0 / shape)")
+            raise ValueError("actor_preact_l2 is implemented by the fused DDPG kernel only (unsupported layer shape)")
 
     # ---- fused step (3 launches with uniform sampling) --------------------------------------------
     def _layer(self, w, name):
@@ -607,7 +606,7 @@ class MlpStepProgram(object):
         self.graphs = None
         self.calls = 0
         # updates per graph replay (single rank, device replay): see ops/dqn_engine.py:DqnStepProgram
-        k = int(os.environ.get("PDA_GRAPH_STEPS", graph_steps) or 1)
+        k = int(graph_steps or 1)
         if self.dp or staged or not use_graph:
             k = 1
         tu = engine.target_update

@@ -86,17 +86,28 @@ def conv_out(h, k, s):
     return (h - k) // s + 1
 
 
+FORCE_GENERIC_CONV1 = False
+
+
+def force_generic_conv1(on):
+    """Test hook: route the Nature conv1 geometry through the generic implicit-GEMM kernels (python and C side)."""
+    global FORCE_GENERIC_CONV1
+    FORCE_GENERIC_CONV1 = bool(on)
+    L = _L()
+    L.pda_force_generic_conv1.argtypes = [ctypes.c_int]
+    L.pda_force_generic_conv1.restype = None
+    L.pda_force_generic_conv1(1 if on else 0)
+
+
 def conv1_specialised(H, W, C, KH, KW, S, O):
-    """True when the whole-image conv1 kernels (csrc/conv1_kernels.hip) cover this layer."""
-    import os
-    return os.environ.get("PDA_CONV1_GENERIC", "0") != "1" and bool(_L().pda_conv1_supported(H, W, C, KH, KW, S, O))
+    """True when the whole-image conv1 kernels (csrc/conv1_kernels.hip) cover this layer.  (FORCE_GENERIC_CONV1: a
+    test hook -- tests/test_gpu_gemm.py runs the Nature geometry through the generic implicit-GEMM kernels too.)"""
+    return not FORCE_GENERIC_CONV1 and bool(_L().pda_conv1_supported(H, W, C, KH, KW, S, O))
 
 
 def cnn_fwd_stack_supported(H, W, C):
     """True when the one-launch conv1 -> conv2 -> conv3 forward (csrc/conv1_kernels.hip) covers this input."""
-    import os
-    return os.environ.get("PDA_FUSED_FWD", "1") != "0" and conv1_specialised(H, W, C, 8, 8, 4, 32) \
-        and bool(_L().pda_cnn_fwd_stack_supported(H, W, C))
+    return conv1_specialised(H, W, C, 8, 8, 4, 32) and bool(_L().pda_cnn_fwd_stack_supported(H, W, C))
 
 
 def cnn_fwd_stack(frames, idx, w1, b1, w2, b2, w3, b3, a1, a2, a3, batch, H, W, C, scale):
@@ -108,8 +119,7 @@ def cnn_fwd_stack(frames, idx, w1, b1, w2, b2, w3, b3, a1, a2, a3, batch, H, W, 
 
 
 def cnn_dgrad_stack_supported(H, W, C):
-    import os
-    return os.environ.get("PDA_FUSED_BWD", "1") != "0" and bool(_L().pda_cnn_dgrad_stack_supported(H, W, C))
+    return not FORCE_GENERIC_CONV1 and bool(_L().pda_cnn_dgrad_stack_supported(H, W, C))
 
 
 def cnn_dgrad_stack_slices(batch):
@@ -308,27 +318,6 @@ def conv_wgrad_pair(dys, xs, gws, gbs, batch, geoms, O, ksplit, slice_strides, b
                           iarr[4], iarr[5], int(O), ss, bs, int(ksplit), _stream())
 
 
-def adam_with_wgrad_pair(dys, xs, gws, gbs, batch, geoms, O, ksplit, slice_strides, bslice_strides, adam, table):
-    """conv_wgrad_pair plus the optimizer workgroups of `table` (segments whose gradients are already final: the
-    fc tail) in one launch (csrc/gemm.hip:pda_adam_with_wgrad_pair).  adam: ops.optim.FlatAdam."""
-    import ctypes as _ct
-    L = _L()
-    if not getattr(L, "_pair_adam_ready", False):
-        L.pda_adam_with_wgrad_pair.argtypes = ([_vp] * 4 + [_ct.c_int] + [_vp] * 6 + [_ct.c_int, _vp, _vp, _ct.c_int] +
-                                               [_vp] * 7 + [_ct.c_int, _vp, _vp, _vp])
-        L.pda_adam_with_wgrad_pair.restype = None
-        L._pair_adam_ready = True
-    cols = list(zip(*geoms))
-    iarr = [(_ct.c_int * 2)(*[int(v) for v in col]) for col in cols]
-    ss = (_ct.c_long * 2)(*[int(v) for v in slice_strides])
-    bs = (_ct.c_long * 2)(*[int(v) for v in bslice_strides])
-    L.pda_adam_with_wgrad_pair(_arr(dys), _arr(xs), _arr(gws), _arr(gbs), int(batch), iarr[0], iarr[1], iarr[2],
-                               iarr[3], iarr[4], iarr[5], int(O), ss, bs, int(ksplit),
-                               _ptr(adam.p), _ptr(adam.g), _ptr(adam.m), _ptr(adam.v), _ptr(adam.shadow),
-                               _ptr(table.segs), _ptr(table.chunks), int(table.nchunks), _ptr(adam.hyper),
-                               _ptr(adam.step_dev), _stream())
-
-
 def conv_wgrad_u8(dy, frames, idx, gw, gb, batch, H, W, C, KH, KW, S, O, scale, ksplit=0, slice_stride=0,
                   bslice_stride=0):
     assert ksplit == 0 or slice_stride >= O * C * KH * KW
@@ -494,8 +483,7 @@ def x3_conv_fwd_u8(frames, idx, w, bias, out, batch, H, W, C, KH, KW, S, O, scal
 
 def x3_cnn_fwd_stack_supported(H, W, C):
     """True when the one-launch fp32-precision conv stack (cnn_fwd_stack_x3_kernel) covers this input."""
-    import os
-    return os.environ.get("PDA_X3_FUSED_FWD", "1") != "0" and cnn_fwd_stack_supported(H, W, C)
+    return cnn_fwd_stack_supported(H, W, C)
 
 
 def x3_cnn_fwd_stack(frames, idx, w1, b1, w2, b2, w3, b3, a1, a2, a3, batch, H, W, C, scale):
@@ -512,8 +500,7 @@ def x3_cnn_fwd_stack(frames, idx, w1, b1, w2, b2, w3, b3, a1, a2, a3, batch, H, 
 
 
 def x3_cnn_dgrad_stack_supported(H, W, C):
-    import os
-    return os.environ.get("PDA_X3_FUSED_BWD", "1") != "0" and bool(_L().pda_cnn_dgrad_stack_supported(H, W, C))
+    return not FORCE_GENERIC_CONV1 and bool(_L().pda_cnn_dgrad_stack_supported(H, W, C))
 
 
 def x3_cnn_dgrad_stack(da3, a2_hi, a1_hi, w3t, w2t, da2, da1, batch, w1=None):

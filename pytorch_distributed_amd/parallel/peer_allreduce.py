@@ -72,11 +72,14 @@ def plan(numel, world, budget=0):
     return sl.value, ch.value, n.value
 
 
-def workgroup_budget():
+def workgroup_budget(workgroups=None):
     """Workgroups per all-reduce launch (0 = the kernel's 224, sized for one rank per GPU).  Ranks that SHARE a card
-    (one-GPU rehearsals: PDA_PEER_WORKGROUPS, set for all ranks alike by whoever starts them) need all their launches
-    resident on it together, or their waits for each other run out."""
-    return int(os.environ.get("PDA_PEER_WORKGROUPS", "0") or 0)
+    (one-GPU rehearsals: knob peer_workgroups / PDA_PEER_WORKGROUPS, set for all ranks alike by whoever starts them)
+    need all their launches resident on it together, or their waits for each other run out."""
+    if workgroups is None:
+        from ..ops.knobs import resolve
+        workgroups = resolve().peer_workgroups
+    return int(workgroups)
 
 
 _regions_created = 0        # per process; every rank creates its regions in the same (collective) order
@@ -86,7 +89,7 @@ class PeerAllReduce(object):
     """In-place SUM all-reduce of ONE fixed fp32 device buffer of `numel` elements over the ranks of `comm`
     (a TorchComm: used only to exchange the 64-byte IPC handles).  wire="bf16" sends slices as bf16."""
 
-    def __init__(self, comm, numel, device, wire="fp32"):
+    def __init__(self, comm, numel, device, wire="fp32", workgroups=None):
         self.comm, self.numel, self.device = comm, int(numel), torch.device(device)
         self.rank, self.world = int(comm.rank), int(comm.world_size)
         if not 2 <= self.world <= MAX_RANKS:
@@ -94,7 +97,7 @@ class PeerAllReduce(object):
         if wire not in ("fp32", "bf16"):
             raise ValueError("wire must be 'fp32' or 'bf16'")
         self.wire_bf16 = 1 if wire == "bf16" else 0
-        self.budget = workgroup_budget()
+        self.budget = workgroup_budget(workgroups)
         self.local, self.peers, self.closed = None, {}, False
         L = _lib()
         torch.cuda.set_device(self.device)
@@ -112,7 +115,7 @@ class PeerAllReduce(object):
         dist.all_gather_object(everyone, mine, group=getattr(comm, "group", None))
         err = None
         if len({e["budget"] for e in everyone}) != 1:
-            err = "ranks disagree on the workgroup budget (PDA_PEER_WORKGROUPS must be the same everywhere)"
+            err = "ranks disagree on the workgroup budget (knob peer_workgroups must be the same everywhere)"
         elif len({e["epoch_base"] for e in everyone}) != 1:
             err = "ranks disagree on the region's epoch base (regions must be created in the same order everywhere)"
         elif any(e["rc"] != 0 for e in everyone):
@@ -221,9 +224,13 @@ def self_test(peer, comm, device):
     return comm.all_agree(ok)
 
 
-def make_grad_allreduce(comm, flat, kind=None, wire="fp32"):
-    """The all-reduce object (`.all_reduce_sum_(flat)`, `.kind`) for one gradient bucket."""
-    kind = (kind or os.environ.get("PDA_DP_ALLREDUCE", "auto")).lower()
+def make_grad_allreduce(comm, flat, kind=None, wire="fp32", workgroups=None):
+    """The all-reduce object (`.all_reduce_sum_(flat)`, `.kind`) for one gradient bucket.  kind: auto | peer | rccl
+    (None: the dp_allreduce knob); workgroups: the peer kernel's workgroup budget (None: the peer_workgroups knob)."""
+    if kind is None:
+        from ..ops.knobs import resolve
+        kind = resolve().dp_allreduce
+    kind = kind.lower()
     gpu_group = (comm is not None and getattr(comm, "world_size", 1) > 1 and flat.is_cuda and dist is not None
                  and dist.is_initialized())
     if kind == "rccl" or not gpu_group:
@@ -233,7 +240,7 @@ def make_grad_allreduce(comm, flat, kind=None, wire="fp32"):
     try:
         if not comm.all_agree(flat.data_ptr() % 16 == 0):
             raise RuntimeError("gradient bucket not 16-byte aligned on every rank")
-        peer = PeerAllReduce(comm, flat.numel(), flat.device, wire=wire)
+        peer = PeerAllReduce(comm, flat.numel(), flat.device, wire=wire, workgroups=workgroups)
         if not self_test(peer, comm, flat.device):      # (collective verdict: the same on every rank)
             peer.close()
             raise RuntimeError("peer all-reduce self-test failed")

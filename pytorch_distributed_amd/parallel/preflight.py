@@ -74,7 +74,9 @@ def _child():
 def choose_dp_graph_mode(timeout_s=150, backend="nccl", port_offset=23):
     """Run the child for this rank; returns "whole" or "split".  Call before the parent
     initialises the GPU.  World size 1 without an explicit request needs no answer."""
-    forced = os.environ.get("PDA_DP_GRAPH")
+    from ..ops.knobs import resolve
+    forced = resolve().dp_graph
+    forced = None if forced == "auto" else forced
     if forced in ("whole", "split"):
         return forced
     env = dict(os.environ)

@@ -189,6 +189,8 @@ class Params(object):
         self.dist_backend = None            # process-group back-end of the learner ranks (None: "nccl" = RCCL on GPUs, gloo on CPU)
         self.allow_shared_gpu = False       # num_learners > visible GPUs: refuse (False) or let ranks share a card (rehearsal)
         self.force_dp = False               # run the data-parallel step program even with one learner (rehearsal)
+        self.engine_knobs = {}              # tuning knobs of the native engines (ops/knobs.py: split-K targets, DP wire
+                                            # format / all-reduce / graph mode, ...); `engine_knobs.<name>=<value>`
         self.graph_steps = 5                # native DQN learner, HBM replay, one rank: updates per hipGraph replay (the
                                             # learner runs up to graph_steps - 1 updates ahead of its step counter)
 
@@ -340,6 +342,9 @@ class Options(Params):
                 continue
             if "." in key:
                 head, field = key.split(".", 1)
+                if head == "engine_knobs":      # engine_knobs.fc1_blocks=128 (validated by ops/knobs.py:resolve)
+                    self.engine_knobs = dict(self.engine_knobs or {}, **{field: val})
+                    continue
                 if head not in _NESTED:
                     raise KeyError("unknown params group %r" % head)
                 setattr(getattr(self, head), field, val)

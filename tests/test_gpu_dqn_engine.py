@@ -256,11 +256,10 @@ def test_multi_step_graph_runs_ahead_and_keeps_target_updates_aligned(eng):
     assert np.isfinite(e.mean_loss())
 
 
-def test_fc_tail_adam_inside_the_wgrad_pair_launch_matches_one_launch_optimizer(eng, monkeypatch):
-    """The single-rank step can run the fc tail's optimizer update inside the conv2/conv3 weight-gradient launch
-    (PDA_PAIR_ADAM=1, opt-in) and the conv head's as a short launch after it: same arithmetic as the one-launch
-    optimizer.  (Not bit for bit: two runs of the SAME step program already differ by ~1e-7 in the gradients --
-    fc1's forward split-K sums arrive in any order -- which Adam's normalised step can amplify to ~1e-6.)"""
+def test_engine_knobs_are_resolved_once_at_construction(eng, monkeypatch):
+    """Tuning knobs come from Options.engine_knobs / PDA_<NAME> through ops/knobs.py when the engine is BUILT; the
+    step itself never reads the environment.  A different fc1 split changes the slab count, not the result."""
+    from pytorch_distributed_amd.ops.knobs import resolve
     B = 128
     s0, s1, tails = make_batch(B, 6)
     mem_n = 512
@@ -268,24 +267,25 @@ def test_fc_tail_adam_inside_the_wgrad_pair_launch_matches_one_launch_optimizer(
     frames = torch.randint(0, 256, (mem_n, 4, 84, 84), dtype=torch.uint8, device="cuda", generator=g)
     rt = tails[torch.arange(mem_n, device="cuda") % B].contiguous()
     outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("PDA_PAIR_ADAM", flag)
+    for blocks in (256, 64):
+        monkeypatch.setenv("PDA_FC1_BLOCKS", str(blocks))
         model, target = make_models(seed=7)
         e = eng.DqnCnnEngine(model, target, B, lr=3e-4, target_update=1000, seed=11)
+        assert e.knobs.fc1_blocks == blocks and resolve().fc1_blocks == blocks
+        monkeypatch.setenv("PDA_FC1_BLOCKS", "999")     # too late: the engine holds its knobs
         e.bind_replay(frames, frames.flip(0).contiguous(), rt, None)
         e.set_size(mem_n)
         prog = eng.DqnStepProgram(e, None, use_graph=True, staged=False, graph_steps=2)
-        assert prog.pair_adam == (flag == "1")
-        init = e.online.flat.clone()
         for _ in range(5):
             prog.step()
         torch.cuda.synchronize()
-        assert e.step_count == 5 and e.online.flat.ne(init).any()
-        outs.append((e.online.flat.clone(), e.grads.clone(), e.adam.m.clone(), e.online.shadow.float()))
-    (p0, g0, m0, s0_), (p1, g1, m1, s1_) = outs
-    assert (p0 - p1).abs().max().item() < 1e-4          # one wrong-signed Adam step would be 2 lr = 6e-4
-    assert rel_err(g1, g0) < 1e-3 and rel_err(m1, m0) < 1e-3
-    assert (s0_ - s1_).abs().max().item() < 1e-2 * s0_.abs().max().item()
+        assert e.knobs.fc1_blocks == blocks and e.step_count == 5
+        outs.append((e.acts.h1_slices, e.online.flat.clone(), e.grads.clone()))
+    (n0, p0, g0), (n1, p1, g1) = outs
+    assert n0 > n1 >= 1
+    assert (p0 - p1).abs().max().item() < 1e-4 and rel_err(g1, g0) < 1e-3
+    with pytest.raises(ValueError):
+        resolve(dp_graph="sideways")
 
 
 def test_batched_inference_matches_model(eng):

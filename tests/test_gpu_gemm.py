@@ -17,6 +17,13 @@ def nn():
     return _nn
 
 
+@pytest.fixture
+def generic_conv1(nn):
+    """Route the Nature conv1 geometry through the generic implicit-GEMM kernels for one test."""
+    yield nn.force_generic_conv1
+    nn.force_generic_conv1(False)
+
+
 def bf(x):
     return x.to(torch.bfloat16).float()
 
@@ -82,10 +89,10 @@ def test_linear_fwd_grouped_tanh(nn):
 
 @pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("batch,use_idx", [(32, True), (5, False), (600, True)])
-def test_conv1_fwd_u8(nn, batch, use_idx, generic, monkeypatch):
+def test_conv1_fwd_u8(nn, batch, use_idx, generic, generic_conv1):
     """generic: the implicit-GEMM loader of gemm.h; otherwise the whole-image kernel of conv1_kernels.hip
     (600 images > 512 workgroups: the per-block image loop)."""
-    monkeypatch.setenv("PDA_CONV1_GENERIC", "1" if generic else "0")
+    generic_conv1(generic)
     assert nn.conv1_specialised(84, 84, 4, 8, 8, 4, 32) == (not generic)
     torch.manual_seed(2)
     mem = torch.randint(0, 256, (64, 4, 84, 84), dtype=torch.uint8, device="cuda")
@@ -275,8 +282,8 @@ def test_cnn_dgrad_stack_with_conv1_wgrad_tail(nn, batch):
 
 @pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("batch", [8, 300])
-def test_conv1_wgrad_u8(nn, batch, generic, monkeypatch):
-    monkeypatch.setenv("PDA_CONV1_GENERIC", "1" if generic else "0")
+def test_conv1_wgrad_u8(nn, batch, generic, generic_conv1):
+    generic_conv1(generic)
     torch.manual_seed(6)
     mem = torch.randint(0, 256, (32, 4, 84, 84), dtype=torch.uint8, device="cuda")
     idx = torch.randint(0, 32, (batch,), dtype=torch.int32, device="cuda")

@@ -1,5 +1,5 @@
 """Time the native DDPG learner step (ops/mlp_engine.py) on HBM-resident replay: fused three-launch step
-(csrc/mlp_fused.hip) vs the layer-by-layer launches (PDA_MLP_FUSED=0).
+(csrc/mlp_fused.hip, --precision bf16) or the fp32 job-list engine (csrc/mlp_f32.hip, --precision fp32).
 
     python tools/bench_mlp_step.py [--batch 64] [--steps 4000] [--graph-steps 5] [--obs 3] [--act 1]
 Prints one JSON line.
