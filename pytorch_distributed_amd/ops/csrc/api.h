@@ -31,7 +31,7 @@ PDA_EXPORT void pda_mlp_stage(const StageJobs* jobs, int njobs, const void* idx,
 PDA_EXPORT void pda_bf16_rows_to_f32(const void* in, long ld_in, void* out, long ld_out, int rows, int cols,
                                      hipStream_t stream);
 
-// whole-image conv1 kernels (conv1_kernels.hip)
+// Nature-CNN kernel family (nature_*.hip, shared header nature_cnn.h)
 PDA_EXPORT int pda_conv1_supported(int H, int W, int C, int KH, int KW, int S, int O);
 PDA_EXPORT void pda_conv1_fwd_u8(const void* const* frames, const void* const* idx, const void* const* w,
                                  const void* const* bias, void* const* out, int ngroups, int batch, int H, int W,

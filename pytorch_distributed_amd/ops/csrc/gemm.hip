@@ -30,7 +30,7 @@ PDA_EXPORT void pda_conv_fwd_u8(const void* const* frames, const void* const* id
                                 const void* const* bias, void* const* out, int ngroups, int batch,
                                 int H, int W, int C, int KH, int KW, int S, int O, float scale, int act,
                                 hipStream_t stream) {
-    // Nature conv1 geometry: the whole-image kernel (conv1_kernels.hip), unless the test hook keeps this loader
+    // Nature conv1 geometry: the whole-image kernel (nature_conv1.hip), unless the test hook keeps this loader
     const bool generic_only = g_force_generic_conv1 != 0;
     if (!generic_only && ngroups <= GEMM_MAX_GROUPS && pda_conv1_supported(H, W, C, KH, KW, S, O)) {
         pda_conv1_fwd_u8(frames, idx, w, bias, out, ngroups, batch, H, W, C, scale, act, stream);

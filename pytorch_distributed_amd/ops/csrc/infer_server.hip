@@ -112,7 +112,7 @@ void enqueue_program(Server& S, int n) {
         const void* x1[1] = {S.a1}; const void* x2[1] = {S.a2}; const void* x3[1] = {S.a3};
         void* o32[1] = {S.h1pre};
         if (pda_cnn_fwd_stack_supported(c.H, c.W, c.C)) {
-            // the three conv layers in one launch, intermediates in LDS (conv1_kernels.hip)
+            // the three conv layers in one launch, intermediates in LDS (nature_fwd_stack.hip)
             void* none[1] = {nullptr};
             pda_cnn_fwd_stack(frames, idx, w0, b0, w1, b1, w2, b2, none, none, o3, 1, n, c.H, c.W, c.C, c.inv_norm, st);
         } else {

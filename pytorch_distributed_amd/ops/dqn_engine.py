@@ -370,7 +370,7 @@ class DqnCnnEngine(object):
         self.deterministic = True
         # conv2 + conv3 weight gradients as two problem groups of ONE launch
         self.pair_wgrad = bool(self.acts.stack_dgrad) or x3
-        # large batches: conv2 + conv3 weight gradients per image with register accumulation (csrc/conv1_kernels.hip)
+        # large batches: conv2 + conv3 weight gradients per image with register accumulation (csrc/nature_wgrad_stack.hip)
         self.stack_wgrad = bool(self.acts.stack_dgrad) and self.B >= self.knobs.wgrad_stack_min and not x3
         # fc1's data gradient in the launch of the two fc weight gradients (small batches: all three under-fill the GPU)
         self.fc_duo = self.B <= 512

@@ -100,13 +100,13 @@ def force_generic_conv1(on):
 
 
 def conv1_specialised(H, W, C, KH, KW, S, O):
-    """True when the whole-image conv1 kernels (csrc/conv1_kernels.hip) cover this layer.  (FORCE_GENERIC_CONV1: a
+    """True when the whole-image conv1 kernels (csrc/nature_conv1.hip) cover this layer.  (FORCE_GENERIC_CONV1: a
     test hook -- tests/test_gpu_gemm.py runs the Nature geometry through the generic implicit-GEMM kernels too.)"""
     return not FORCE_GENERIC_CONV1 and bool(_L().pda_conv1_supported(H, W, C, KH, KW, S, O))
 
 
 def cnn_fwd_stack_supported(H, W, C):
-    """True when the one-launch conv1 -> conv2 -> conv3 forward (csrc/conv1_kernels.hip) covers this input."""
+    """True when the one-launch conv1 -> conv2 -> conv3 forward (csrc/nature_fwd_stack.hip) covers this input."""
     return conv1_specialised(H, W, C, 8, 8, 4, 32) and bool(_L().pda_cnn_fwd_stack_supported(H, W, C))
 
 

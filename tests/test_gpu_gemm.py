@@ -90,7 +90,7 @@ def test_linear_fwd_grouped_tanh(nn):
 @pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("batch,use_idx", [(32, True), (5, False), (600, True)])
 def test_conv1_fwd_u8(nn, batch, use_idx, generic, generic_conv1):
-    """generic: the implicit-GEMM loader of gemm.h; otherwise the whole-image kernel of conv1_kernels.hip
+    """generic: the implicit-GEMM loader of gemm.h; otherwise the whole-image kernel of nature_conv1.hip
     (600 images > 512 workgroups: the per-block image loop)."""
     generic_conv1(generic)
     assert nn.conv1_specialised(84, 84, 4, 8, 8, 4, 32) == (not generic)
