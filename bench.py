@@ -86,6 +86,11 @@ def parse_args(argv=None):
                     help="also time the Distributed-DDPG learner step (config 7 shapes: 3-dim obs, 1-dim action, batch "
                          "64, HBM replay) on the fp32 job-list engine and the fused bf16 engine: \"ddpg_value\" "
                          "(fp32, the reference's precision) and \"ddpg_bf16_value\", updates/s (auto: 1 GPU, native)")
+    ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"],
+                    help="also run the other BASELINE.json learner configs as short child benches and report them as "
+                         "extra keys: \"per_value\" (config 4: Ape-X prioritized replay, batch 128) and "
+                         "\"b4096_value\" (config 5: batch 4096, prioritized), fp32-class engine, updates/s "
+                         "(auto: 1 GPU, native, --config 2)")
     ap.add_argument("--launcher", action="store_true", help="start the rank(s) as child processes even for --gpus 1")
     ap.add_argument("--launch-timeout", type=float, default=900.0)
     return ap.parse_args(argv)
@@ -220,6 +225,24 @@ def run_ddpg_step(precision, timeout=120.0):
             return json.loads(line)
     return {"error": "ddpg step bench printed no result (exit %s): %s" % (p.returncode,
                                                                           p.stderr.decode(errors="replace")[-300:])}
+
+
+def run_child_bench(extra_args, timeout=240.0):
+    """This script once more, as a child, for another config -> its JSON line (dict) or {"error": ...}."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--node", "off", "--ddpg", "off", "--extras", "off",
+           "--precision", "fp32"] + list(extra_args)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "child bench did not finish within %.0f s" % timeout}
+    for line in reversed(p.stdout.decode(errors="replace").splitlines()):
+        if line.startswith("{"):
+            r = json.loads(line)
+            r["exit_code"] = p.returncode
+            return r
+    return {"error": "child bench printed no result (exit %s): %s" % (p.returncode,
+                                                                      p.stderr.decode(errors="replace")[-300:])}
 
 
 def timed_windows(core, comm, steps, min_time, max_windows, sync, reduce_max):
@@ -375,6 +398,14 @@ def run_rank(a):
                 if ar is not None and hasattr(ar, "error"):
                     errs += int(bool(ar.error()))
         extra["dp_allreduce_errors"] = int(reduce_max(float(errs)))
+        # self-diagnosis for the scaling runs: what the start-up measurement chose for the fc-tail bucket (and the
+        # candidates' times), and where the step's communication goes (per-bucket all-reduce, exposed waits)
+        extra["dp_wire_choice"] = getattr(prog, "comm_report", None)
+        extra["dp_grad_allreduce_dtype"] = getattr(prog, "grad_dtype", None)
+        if hasattr(prog, "measure_comm") and os.environ.get("PDA_BENCH_COMM_PROBE", "1") != "0":
+            comm_us = prog.measure_comm(steps=20)
+            extra["dp_comm_us"] = {k: (round(reduce_max(v), 2) if isinstance(v, float) else v)
+                                   for k, v in comm_us.items()}
         if extra["dp_allreduce_errors"] and rank == 0:
             print("[bench] the peer all-reduce reported timed-out waits: the DP result is NOT valid; rerun with "
                   "--allreduce rccl", file=sys.stderr, flush=True)
@@ -462,6 +493,23 @@ def run_rank(a):
                               "replay": "HBM-resident, uniform", "unit": "updates/s",
                               "dtype": {"ddpg_value": "fp32 (v_mfma_f32_16x16x4_f32: exact fp32 products and sums)",
                                         "ddpg_bf16_value": "bf16 operands, fp32 accumulate"}}
+    if rank == 0 and (a.extras == "on" or (a.extras == "auto" and use_cuda and world == 1 and a.compute == "native"
+                                           and a.config == 2)):
+        # BASELINE.json configs 4 and 5 (learner side): each measured for <= ~3 s in a child of its own
+        for key, extra in (("per_value", ["--config", "4", "--batch", "128", "--steps", "1000", "--warmup", "200",
+                                          "--min-time", "1.5"]),
+                           ("b4096_value", ["--config", "5", "--batch", "4096", "--steps", "50", "--warmup", "10",
+                                            "--min-time", "1.5"])):
+            r = run_child_bench(extra)
+            out[key] = r.get("value")
+            out[key.replace("_value", "_ms_per_step")] = r.get("ms_per_step")
+            out[key.replace("_value", "_exit_code")] = r.get("exit_code")
+            if "error" in r:
+                out[key + "_error"] = r["error"]
+        out["extras_config"] = {"per_value": "config 4 learner: prioritized replay (HIP sum/min tree, 50 k transitions "
+                                             "HBM-resident), batch 128, fp32-class engine, updates/s",
+                                "b4096_value": "config 5 learner: batch 4096, prioritized replay, fp32-class engine, "
+                                               "updates/s (x 4096 = samples/s)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
 

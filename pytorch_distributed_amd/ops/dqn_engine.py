@@ -728,24 +728,34 @@ class DqnStepProgram(object):
             self.head = e.grads[:e.tail_start]
             # the fc tail is 95 % of the gradient bytes (6.4 MB fp32): optionally all-reduced as bf16 -- half the
             # bytes on the xGMI links, which at ~0.1 ms of compute per step is what bounds data-parallel scaling.
-            # (knob dp_grad_dtype = bf16 | fp32, default fp32: the two conversion launches cost ~20 us per step in the
-            # 1-rank rehearsal -- 9.2k vs 7.8k updates/s -- so it only pays where the all-reduce saves more than that.)
-            self.grad_dtype = knobs.dp_grad_dtype
             # The all-reduce itself: the one-kernel xGMI peer all-reduce (parallel/peer_allreduce.py: every rank maps
             # every peer's hand-off region through hipIpc; two hops over all links, replayable inside the step graph)
             # when it passes its self-test on every rank, else the process group's (RCCL ring / gloo).
-            # knob dp_allreduce = auto | peer | rccl.
-            from ..parallel.peer_allreduce import make_grad_allreduce
-            kind = knobs.dp_allreduce
+            # Knobs dp_allreduce = auto | peer | rccl, dp_grad_dtype = measure | fp32 | bf16 (ops/knobs.py): with
+            # "measure" the candidates are timed here, on the real bucket, and the fastest wins.
+            from ..parallel.peer_allreduce import choose_grad_allreduce, make_grad_allreduce
+            kind, wg = knobs.dp_allreduce, knobs.peer_workgroups
             if not hasattr(comm, "backend") or not self.tail.is_cuda:
                 kind = "rccl"           # FakeComm / CPU tensors: the communicator's own reduce
-            self.ar_tail = make_grad_allreduce(comm, self.tail, kind, wire=self.grad_dtype,
-                                               workgroups=knobs.peer_workgroups)
-            self.ar_head = make_grad_allreduce(comm, self.head, kind, workgroups=knobs.peer_workgroups)
+            self.comm_report, self._spare_allreduces = {"us": {}, "chosen": None}, []
+            if knobs.dp_grad_dtype == "measure" and kind != "rccl":
+                wires = ("fp32",) if e.x3 else ("fp32", "bf16")
+                self.ar_tail, self.comm_report, self._spare_allreduces = choose_grad_allreduce(
+                    comm, self.tail, kind, wires, wg)
+                head_kind = "rccl" if self.ar_tail.kind == "rccl" else kind
+                self.grad_dtype = "bf16" if self.ar_tail.kind == "peer-bf16" else "fp32"
+            else:
+                self.grad_dtype = "fp32" if knobs.dp_grad_dtype == "measure" else knobs.dp_grad_dtype
+                self.ar_tail = make_grad_allreduce(comm, self.tail, kind, wire=self.grad_dtype, workgroups=wg)
+                head_kind = kind
+                self.comm_report["chosen"] = self.ar_tail.kind
+            self.ar_head = make_grad_allreduce(comm, self.head, head_kind, workgroups=wg)
             self.allreduce_kind = self.ar_tail.kind
             self.peer = self.allreduce_kind.startswith("peer")
             if getattr(comm, "backend", None) != "nccl" and not self.peer:
                 self.grad_dtype = "fp32"        # host back-ends (gloo rehearsals, tests) reduce the fp32 buffer
+            # (process-group all-reduce with a bf16 wire: two conversion launches around the collective -- ~20 us per
+            # step in the 1-rank rehearsal, 9.2k vs 7.8k updates/s -- so it only pays where the wire saves more)
             self.tail16 = (torch.empty_like(self.tail, dtype=BF16)
                            if self.grad_dtype == "bf16" and not self.peer else None)
 
@@ -791,34 +801,79 @@ class DqnStepProgram(object):
             graphs.append(gr)
         return graphs
 
-    def _run_dp(self, a, b):
+    def _run_dp(self, a, b, probe=None):
         """One data-parallel step on the current stream + the comm stream.  Works eagerly, with
         a/b replaying captured graphs, and -- because every cross-stream edge is an event --
-        inside a stream capture, where the comm stream becomes a forked branch of ONE graph."""
+        inside a stream capture, where the comm stream becomes a forked branch of ONE graph.
+        probe: dict of timing events (measure_comm) recorded at the hand-over points of an EAGER step."""
         e, cur = self.e, torch.cuda.current_stream()
+
+        def mark(name, stream):
+            if probe is not None:
+                probe[name].record(stream)
+
+        mark("step0", cur)
         a()
         self.fc_done.record(cur)
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(self.fc_done)
+            mark("tail0", self.comm_stream)
             if self.tail16 is not None:
                 self.tail16.copy_(self.tail)
                 self.comm.all_reduce_sum_(self.tail16)
                 self.tail.copy_(self.tail16)
             else:
                 self.ar_tail.all_reduce_sum_(self.tail)     # (peer kernel: bf16 wire conversion happens in it)
+            mark("tail1", self.comm_stream)
             self.tail_done.record(self.comm_stream)
         b()
         self.conv_done.record(cur)
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(self.conv_done)
+            mark("head0", self.comm_stream)
             self.ar_head.all_reduce_sum_(self.head)
+            mark("head1", self.comm_stream)
             self.head_done.record(self.comm_stream)
+        mark("wait_tail", cur)
         cur.wait_event(self.tail_done)
         e.adam.step(table=self.tail_table)          # fc tail update runs under the conv all-reduce
+        mark("wait_head", cur)
         cur.wait_event(self.head_done)
         e.adam.step(table=self.head_table, extras=self.dp_extras)     # + next step's index draw
         e.post_update(self.staged)
+        mark("step1", cur)
         self.presampled = self.dp_extras is not None
+
+    def measure_comm(self, steps=20):
+        """Where a data-parallel step's communication goes, from `steps` EAGER steps with timing events at the
+        hand-over points (these steps are real updates; call it outside any timed region).  -> dict, us per step:
+          allreduce_tail_us / allreduce_head_us   the two gradient buckets' all-reduces, on the comm stream
+          exposed_tail_us / exposed_head_us       how long the main stream had nothing to do but wait for each
+                                                  (0 = the all-reduce was hidden under the conv backward / the fc
+                                                  tail's optimizer update)
+          step_us                                 the whole eager step (launch-bound: slower than the graph replay)"""
+        if not self.dp:
+            return {}
+        names = ("step0", "tail0", "tail1", "head0", "head1", "wait_tail", "wait_head", "step1")
+        acc = dict.fromkeys(("allreduce_tail_us", "allreduce_head_us", "exposed_tail_us", "exposed_head_us",
+                             "step_us"), 0.0)
+        dev = self.e.device
+        for _ in range(int(steps)):
+            probe = {n: torch.cuda.Event(enable_timing=True) for n in names}
+            self._run_dp(self._part_a, self._part_b, probe=probe)
+            torch.cuda.synchronize(dev)
+            acc["allreduce_tail_us"] += 1e3 * probe["tail0"].elapsed_time(probe["tail1"])
+            acc["allreduce_head_us"] += 1e3 * probe["head0"].elapsed_time(probe["head1"])
+            acc["exposed_tail_us"] += max(0.0, 1e3 * probe["wait_tail"].elapsed_time(probe["tail1"]))
+            acc["exposed_head_us"] += max(0.0, 1e3 * probe["wait_head"].elapsed_time(probe["head1"]))
+            acc["step_us"] += 1e3 * probe["step0"].elapsed_time(probe["step1"])
+            self.e.loss_steps += 1
+            self.e.step_count += 1
+        out = {k: round(v / max(int(steps), 1), 2) for k, v in acc.items()}
+        out["steps"] = int(steps)
+        out["note"] = ("eager steps with events; the exposed figures are upper bounds for the graph-replayed step, "
+                       "whose compute side is shorter")
+        return out
 
     def _dp_whole(self):
         self._run_dp(self._part_a, self._part_b)
@@ -849,6 +904,9 @@ class DqnStepProgram(object):
                 ar.clear_error()
             ar.close()
             setattr(self, name, _RcclAllReduce(comm))
+        for ar in getattr(self, "_spare_allreduces", []):
+            ar.close()
+        self._spare_allreduces = []
         self.allreduce_kind = self.ar_tail.kind
         self.peer = False
         self.grad_dtype = "fp32"

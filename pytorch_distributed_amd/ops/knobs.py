@@ -27,10 +27,14 @@ DEFAULTS = {
     "wgrad_stack_min": 4096,
     # graph replays the host may run ahead of the GPU (profiles/r3_node_learner_loop.txt)
     "max_inflight_replays": 3,
-    # data parallel: gradient wire format of the fc tail (fp32 | bf16), the all-reduce (auto | peer | rccl), how the
-    # step is captured (auto | whole | split; bench.py / the learner set it from parallel/preflight.py), and the peer
-    # kernel's workgroup budget (0 = its own plan; shared-card rehearsals of 8 ranks need <= 64)
-    "dp_grad_dtype": "fp32",
+    # data parallel: gradient wire format of the fc tail (fp32 | bf16 | measure), the all-reduce (auto | peer | rccl),
+    # how the step is captured (auto | whole | split; bench.py / the learner set it from parallel/preflight.py), and
+    # the peer kernel's workgroup budget (0 = its own plan; shared-card rehearsals of 8 ranks need <= 64).
+    # "measure": the candidates are TIMED on the real fc-tail bucket when the step program is built -- the peer kernel
+    # with an fp32 wire, with a bf16 wire (bf16 engines only: the fp32-class engine keeps exact fp32 sums) and, with
+    # dp_allreduce=auto on an RCCL group, the process group's all-reduce -- and the fastest is used
+    # (parallel/peer_allreduce.py:choose_grad_allreduce; the timings go into bench.py's JSON as "dp_wire_choice").
+    "dp_grad_dtype": "measure",
     "dp_allreduce": "auto",
     "dp_graph": "auto",
     "peer_workgroups": 0,
@@ -40,7 +44,7 @@ DEFAULTS = {
     "learner_prof": 0,
 }
 
-_CHOICES = {"dp_grad_dtype": ("fp32", "bf16"), "dp_allreduce": ("auto", "peer", "rccl"),
+_CHOICES = {"dp_grad_dtype": ("fp32", "bf16", "measure"), "dp_allreduce": ("auto", "peer", "rccl"),
             "dp_graph": ("auto", "whole", "split")}
 
 

@@ -255,6 +255,57 @@ def make_grad_allreduce(comm, flat, kind=None, wire="fp32", workgroups=None):
     return peer
 
 
+def _time_allreduce(ar, flat, comm, iters=8, warm=2):
+    """us per all-reduce of `flat` through `ar`, the slowest rank's figure (collective)."""
+    for _ in range(warm):
+        ar.all_reduce_sum_(flat)
+    torch.cuda.synchronize(flat.device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ar.all_reduce_sum_(flat)
+    e1.record()
+    torch.cuda.synchronize(flat.device)
+    us = 1e3 * e0.elapsed_time(e1) / iters
+    return comm.agree_max(int(us * 10.0 + 0.5)) / 10.0
+
+
+def choose_grad_allreduce(comm, flat, kind="auto", wires=("fp32",), workgroups=None):
+    """Pick the all-reduce of one gradient bucket BY MEASUREMENT on the real buffer: the peer kernel with each wire
+    format in `wires`, and (kind == "auto", RCCL back-end) the process group's all-reduce.  Every candidate is timed on
+    every rank, the slowest rank's time counts, all ranks take the same decision.
+    -> (all-reduce object, report, the unused candidates).
+    `flat` is summed in place a few times: call this while it holds zeros (engine construction)."""
+    report = {"us": {}, "chosen": None}
+    cands = {}
+    if kind in ("auto", "peer"):
+        for wire in wires:
+            try:
+                ar = make_grad_allreduce(comm, flat, "peer", wire=wire, workgroups=workgroups)
+            except (RuntimeError, ValueError, OSError) as exc:
+                if kind == "peer":
+                    raise
+                report["peer_%s_error" % wire] = str(exc)[:200]
+                continue
+            cands[ar.kind] = ar
+    if kind in ("auto", "rccl") and (kind == "rccl" or getattr(comm, "backend", None) == "nccl" or not cands):
+        cands["rccl"] = _RcclAllReduce(comm)
+    for name in sorted(cands):
+        if len(cands) > 1:
+            report["us"][name] = _time_allreduce(cands[name], flat, comm)
+    if len(cands) > 1:
+        best = min(sorted(cands), key=lambda k: report["us"][k])
+    else:
+        best = next(iter(cands))
+    report["chosen"] = best
+    # The candidates that lost stay mapped until the caller closes them at shutdown (-> third return value): freeing a
+    # region and mapping the next one right away made the NEXT region's self-test fail on this runtime (a peer's
+    # IPC mapping of the freed region's address range outlives the free).
+    spare = [ar for name, ar in cands.items() if name != best]
+    flat.zero_()
+    return cands[best], report, spare
+
+
 # ---- multi-process check: N ranks, all on one GPU or one each -----------------------------------------------------
 def _worker():
     """`python -m pytorch_distributed_amd.parallel.peer_allreduce`: RANK / WORLD_SIZE / MASTER_PORT from the

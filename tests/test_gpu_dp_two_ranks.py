@@ -56,12 +56,25 @@ def test_two_rank_dp_with_the_peer_allreduce_in_one_graph(precision):
     assert out.returncode == 0, out.stderr.decode(errors="replace")[-2000:]
     res = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][0])
     assert res["n_gpus"] == 2 and res["config"]["engine"] == "DqnNativeCore" and res["config"]["precision"] == precision
-    assert res["dp_allreduce"] == "peer-fp32" and res["dp_graph"] == "whole"
+    # the wire format of the fc-tail bucket is chosen by a start-up measurement on the real bucket (knob
+    # dp_grad_dtype=measure): the fp32-class engine only considers the exact fp32 wire
+    choice = res["dp_wire_choice"]
+    assert res["dp_allreduce"] == choice["chosen"] and res["dp_graph"] == "whole"
+    if precision == "fp32":
+        assert res["dp_allreduce"] == "peer-fp32" and res["dp_grad_allreduce_dtype"] == "fp32"
+    else:
+        assert set(choice["us"]) == {"peer-fp32", "peer-bf16"} and all(v > 0 for v in choice["us"].values())
+        assert res["dp_allreduce"] == min(choice["us"], key=choice["us"].get)
+    # ... and the step reports where its communication goes
+    cu = res["dp_comm_us"]
+    assert cu["steps"] == 20 and cu["allreduce_tail_us"] > 0 and cu["allreduce_head_us"] > 0
+    assert cu["exposed_tail_us"] >= 0 and cu["exposed_head_us"] >= 0 and cu["step_us"] > cu["allreduce_tail_us"]
     assert res["config"]["steps_per_graph"] == 5
     assert res["dp_param_max_abs_diff_across_ranks"] == 0.0
     assert res["ranks_distinct"] is True
     assert res["final_loss"] == res["final_loss"] and res["value"] > 0
-    print(json.dumps({k: res[k] for k in ("value", "ms_per_step", "dp_allreduce", "dp_graph")}))
+    print(json.dumps({k: res[k] for k in ("value", "ms_per_step", "dp_allreduce", "dp_graph", "dp_wire_choice",
+                                          "dp_comm_us")}))
 
 
 @pytest.mark.gpu
@@ -80,7 +93,8 @@ def test_eight_rank_dp_step_on_one_card():
     assert out.returncode == 0, out.stderr.decode(errors="replace")[-2000:]
     res = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][0])
     assert res["n_gpus"] == 8 and res["config"]["global_batch"] == 8 * 128
-    assert res["dp_allreduce"] == "peer-fp32" and res["dp_graph"] == "whole"
+    assert res["dp_allreduce"] in ("peer-fp32", "peer-bf16") and res["dp_graph"] == "whole"
+    assert res["dp_wire_choice"]["chosen"] == res["dp_allreduce"]
     assert res["dp_param_max_abs_diff_across_ranks"] == 0.0 and res["dp_allreduce_errors"] == 0
     assert res["rccl_ranks"] == 8 and res["ranks_distinct"] is True and res["rank_id_min_max_sum"] == [0, 7, 28]
     assert res["final_loss"] == res["final_loss"] and res["value"] > 0
