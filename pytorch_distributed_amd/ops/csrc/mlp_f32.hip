@@ -48,6 +48,8 @@ struct F32Job {
     const float* b; long b_sr, b_sj;
     int I, J, R;                        // output rows, output columns, reduction length
     float* c; long c_ld; int c_col0;    // C[i c_ld + c_col0 + j]
+    float c_scale;                      // forward: act(c_scale C + bias) (the 1 / norm_val of a raw input layer);
+                                        // weight gradient: dW = c_scale * A^T B (the same factor, on the input side)
     const float* bias;                  // forward: per output column (may be null)
     const float* yin; long yin_ld;      // data gradient: the activation OUTPUT at (i, j), for act'
     int act, kind;
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_f32_rows_kernel(F32Launch L) {
     const int i = ie, j = je;
     const bool ok = oke;
     if (KIND == KIND_FWD) {
-        v = act_fwd(v + e_bias, J.act);
+        v = act_fwd(v * J.c_scale + e_bias, J.act);
         if (J.nar_w != nullptr) {
             for (int k = 0; k < J.nar_n; ++k) {
                 float sdot = ok ? v * (k == 0 ? e_nar : J.nar_w[(long)k * J.nar_ld + j]) : 0.f;
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_f32_wgrad_kernel(F32Launch L) {
         for (int w = 0; w < NW; ++w) sb += bsum[w][threadIdx.x];
         J.gb[i0 + threadIdx.x] = sb;
     }
-    if (i < J.I && j < J.J) J.c[(long)i * J.c_ld + J.c_col0 + j] = v;
+    if (i < J.I && j < J.J) J.c[(long)i * J.c_ld + J.c_col0 + j] = v * J.c_scale;
 }
 
 }  // namespace
@@ -510,6 +512,7 @@ PDA_EXPORT int pda_mlp_f32_launch(const void* launch_in, hipStream_t stream) {
     for (int k = 0; k < L.n; ++k) {
         F32Job& j = L.j[k];
         if (j.I <= 0 || j.J <= 0 || j.R <= 0 || j.kind != kind || kind < KIND_FWD || kind > KIND_WGRAD) return -2;
+        if (j.c_scale == 0.f) j.c_scale = 1.f;
         maxchunks = max(maxchunks, (j.R + 15) / 16);
         special = special || j.p_q != nullptr || j.t_part != nullptr;
         if ((j.p_q != nullptr && kind != KIND_DGRAD) || (j.t_part != nullptr && kind != KIND_FWD) ||

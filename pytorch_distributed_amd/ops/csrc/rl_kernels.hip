@@ -31,6 +31,9 @@ struct DqnHeadArgs {
     // fc1 split-K sums delivered as slabs (pda_linear_fwd_slab): h1pre_*[s * h1_slice_stride + ...], s < h1_slices,
     // added here in slice order; 0 = one atomically accumulated buffer that this kernel zeroes after reading
     int h1_slices; long h1_slice_stride;
+    // fp32 learners (ops/mlp_f32_engine.py): the same three outputs as plain fp32 rows (null: not written); the bf16
+    // pointers above may then be null
+    float* h1_f32; float* dh1_f32; float* dq_f32;
 };
 
 // One WORKGROUP (4 waves) per sample: thread t owns hidden columns t PER .. t PER + PER - 1 (PER = HID / 256).
@@ -196,7 +199,14 @@ __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
     float dv[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) dv[j] = h0[j] > 0.f ? dqa * wa[j] : 0.f;
-    if constexpr (PER == 2) {
+    if (p.h1_f32 != nullptr) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { p.h1_f32[row + j] = h0[j]; p.dh1_f32[row + j] = dv[j]; }
+        if (tid < p.dq_ld) p.dq_f32[(long)b * p.dq_ld + tid] = tid == act ? dqa : 0.f;
+    }
+    if (p.h1_on0 == nullptr) {
+        // (fp32 outputs only)
+    } else if constexpr (PER == 2) {
         const uint32_t hw = pack2bf(h0[0], h0[1]), dw = pack2bf(dv[0], dv[1]);
         *reinterpret_cast<uint32_t*>(p.h1_on0 + row) = hw;
         *reinterpret_cast<uint32_t*>(p.dh1 + row) = dw;
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(256) void dqn_head_kernel(DqnHeadArgs p) {
             }
         }
     }
-    if (tid < p.dq_ld) {
+    if (tid < p.dq_ld && p.dq != nullptr) {
         const float dq = tid == act ? dqa : 0.f;
         const bf16_t dh = f2bf(dq);
         p.dq[(long)b * p.dq_ld + tid] = dh;

@@ -61,7 +61,8 @@ class _HeadArgs(ctypes.Structure):     # mirrors DqnHeadArgs in csrc/rl_kernels.
                 ("B", ctypes.c_int), ("HID", ctypes.c_int), ("A", ctypes.c_int),
                 ("rng_counter", _vp), ("opt_step", _vp),
                 ("h1_plane", ctypes.c_long), ("dh1_plane", ctypes.c_long), ("dq_plane", ctypes.c_long),
-                ("h1_slices", ctypes.c_int), ("h1_slice_stride", ctypes.c_long)]
+                ("h1_slices", ctypes.c_int), ("h1_slice_stride", ctypes.c_long),
+                ("h1_f32", _vp), ("dh1_f32", _vp), ("dq_f32", _vp)]
 
 
 class _ActArgs(ctypes.Structure):      # mirrors ActHeadArgs

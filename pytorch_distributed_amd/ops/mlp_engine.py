@@ -719,10 +719,11 @@ class MlpNativeCore(object):
                                      actor_l2=float(getattr(ap, "actor_preact_l2", 0.0) or 0.0))
             assert self.engine.A == a
         else:
-            if precision != "bf16":
-                # the MLP-DQN engine multiplies bf16 operands; it is not used when fp32 was asked for
-                raise ValueError("the native dqn-mlp engine is bf16-only: precision=%r needs compute='torch'" % precision)
-            self.engine = DqnMlpEngine(model, target_model, ap.batch_size, lr=ap.lr, weight_decay=ap.weight_decay,
+            if precision == "fp32":
+                from .mlp_f32_engine import DqnMlpEngineF32 as dqn_cls
+            else:
+                dqn_cls = DqnMlpEngine
+            self.engine = dqn_cls(model, target_model, ap.batch_size, lr=ap.lr, weight_decay=ap.weight_decay,
                                        clip=ap.clip_grad, double=ap.enable_double,
                                        target_update=ap.target_model_update, per=per, seed=seed, tail_offsets=offs)
         self.on_device = hasattr(memory, "tails") and getattr(memory, "attached", False) and memory.tails.is_cuda
@@ -769,21 +770,14 @@ class MlpNativeCore(object):
 
 
 def make_mlp_native_core(kind, args, model, target_model, memory, comm):
-    """The native core for an MLP agent, or None when the caller should use the fp32 torch core (which is how
-    precision='fp32' is honoured for dqn-mlp under compute='auto': never by silently running bf16)."""
+    """The native core for an MLP agent (fp32: ops/mlp_f32_engine.py, bf16: the engines above), or None when the
+    layer shapes are outside what the native engines cover (the caller then uses the fp32 torch core)."""
     precision = str(getattr(args, "precision", "fp32"))
     if precision not in ("fp32", "bf16"):
         raise ValueError("precision must be 'fp32' or 'bf16', not %r" % (precision,))
     if kind == "ddpg" and args.model_type == "ddpg-mlp":
         return MlpNativeCore("ddpg", args, model, target_model, memory, comm)
     if kind == "dqn" and args.model_type == "dqn-mlp":
-        if precision != "bf16":
-            if getattr(args, "compute", "auto") == "native":
-                raise ValueError("compute='native' with precision='fp32' is not available for dqn-mlp (its native engine "
-                                 "is bf16-only): use precision='bf16' or compute='auto' / 'torch'")
-            print("[learner] dqn-mlp at precision=fp32: using the fp32 torch core (the native MLP-DQN engine is "
-                  "bf16-only; precision=bf16 selects it)", flush=True)
-            return None
         try:
             return MlpNativeCore("dqn", args, model, target_model, memory, comm)
         except ValueError:

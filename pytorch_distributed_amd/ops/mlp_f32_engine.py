@@ -39,7 +39,7 @@ class _Job(ctypes.Structure):           # mirrors F32Job in csrc/mlp_f32.hip
     _fields_ = [("a", _vp), ("a_si", ctypes.c_long), ("a_sr", ctypes.c_long),
                 ("b", _vp), ("b_sr", ctypes.c_long), ("b_sj", ctypes.c_long),
                 ("I", ctypes.c_int), ("J", ctypes.c_int), ("R", ctypes.c_int),
-                ("c", _vp), ("c_ld", ctypes.c_long), ("c_col0", ctypes.c_int),
+                ("c", _vp), ("c_ld", ctypes.c_long), ("c_col0", ctypes.c_int), ("c_scale", ctypes.c_float),
                 ("bias", _vp), ("yin", _vp), ("yin_ld", ctypes.c_long),
                 ("act", ctypes.c_int), ("kind", ctypes.c_int), ("gb", _vp),
                 ("x_src", _vp), ("x_ld", ctypes.c_long), ("x_col0", ctypes.c_int), ("x_rows", ctypes.c_int),
@@ -109,10 +109,11 @@ def _tiles(n):
     return (int(n) + 15) // 16
 
 
-def fwd_job(x, w, bias, out, rows, N, K, out_col0=0, act=ACT_TANH, x_ld=None, gather=None, gather_mod=0):
-    """out[:, out_col0 : out_col0 + N] = act(x[:rows, :K] @ w.T + bias); x / out: fp32 2-D buffers, w: [N][K].
+def fwd_job(x, w, bias, out, rows, N, K, out_col0=0, act=ACT_TANH, x_ld=None, gather=None, gather_mod=0, scale=1.0):
+    """out[:, out_col0 : out_col0 + N] = act(scale * x[:rows, :K] @ w.T + bias); x / out: fp32 2-D buffers, w: [N][K].
     gather / gather_mod: row i of x is x[gather[i % gather_mod]] (replay rows through the sampled indices)."""
     j = _Job()
+    j.c_scale = float(scale)
     j.a, j.a_si, j.a_sr = x.data_ptr(), (x.stride(0) if x_ld is None else int(x_ld)), 1
     j.b, j.b_sr, j.b_sj = w.data_ptr(), 1, w.stride(0)
     j.I, j.J, j.R = int(rows), int(N), int(K)
@@ -143,6 +144,7 @@ def dgrad_job(dy, w, yin, dx, rows, Nout, Kin, act=ACT_TANH):
     """dx[:rows, :Kin] = (dy[:rows, :Nout] @ w) * act'(yin); w: [Nout][Kin] fp32 master.  dy None: the job gets a
     producer (with_producer) instead of an A operand in memory."""
     j = _Job()
+    j.c_scale = 1.0
     if dy is not None:
         j.a, j.a_si, j.a_sr = dy.data_ptr(), dy.stride(0), 1
     j.b, j.b_sr, j.b_sj = w.data_ptr(), w.stride(0), 1
@@ -163,9 +165,11 @@ def with_producer(j, p, w_narrow, n, y, out, act=ACT_TANH, head=False):
     return j
 
 
-def wgrad_job(dy, x, gw, gb, rows, Nout, Kin):
-    """gw[Nout][Kin] = dy[:rows, :Nout].T @ x[:rows, :Kin], gb[Nout] = column sums of dy (views of the flat gradient)."""
+def wgrad_job(dy, x, gw, gb, rows, Nout, Kin, scale=1.0):
+    """gw[Nout][Kin] = scale * dy[:rows, :Nout].T @ x[:rows, :Kin], gb[Nout] = column sums of dy (views of the flat
+    gradient)."""
     j = _Job()
+    j.c_scale = float(scale)
     j.a, j.a_si, j.a_sr = dy.data_ptr(), 1, dy.stride(0)
     j.b, j.b_sr, j.b_sj = x.data_ptr(), x.stride(0), 1
     j.I, j.J, j.R = int(Nout), int(Kin), int(rows)
@@ -352,6 +356,165 @@ class DdpgMlpEngineF32(_EngineBase):
         else:
             self.adam.step(tick=tick)
             polyak_(self.target.flat, self.online.flat, self.tau, self.target.table, self.target.shadow)
+        self._finish_update(staged)
+
+    def hard_target_update(self):
+        polyak_(self.target.flat, self.online.flat, 1.0, self.target.table, self.target.shadow)
+
+
+# =====================================================================================
+# MLP DQN at fp32 (dqn-mlp: D -> H -> H -> H -> A, relu)
+# =====================================================================================
+class DqnMlpEngineF32(_EngineBase):
+    """Distributed-DQN learner step for the MLP Q-network in fp32 end to end -- the reference learner's arithmetic
+    (/root/reference/core/single_processes/dqn_learner.py:60-96, core/models/dqn_mlp_model.py) -- on the same job-list
+    kernels as DdpgMlpEngineF32:
+
+      launch 1   critic.0 of {online(s0), target(s_n)[, online(s_n)]} reading the replay rows through the sampled
+                 indices (x 1 / norm_val in the epilogue); extra workgroups stage s0 for the weight gradient
+      launch 2-3 critic.2, critic.4 (the last one leaves the pre-activation: the head adds bias + relu)
+      launch 4   dqn_head_kernel (csrc/rl_kernels.hip): fc head, double / plain n-step target, loss, dQ, PER leaves,
+                 fp32 outputs
+      launch 5-6 the two data gradients;  launch 7: all four weight (+ bias) gradients;  launch 8: Adam + index draw
+    """
+    precision = "fp32"
+
+    def __init__(self, model, target_model, batch_size, lr=1e-4, weight_decay=0.0, clip=float("inf"), double=False,
+                 target_update=250, per=None, seed=0, tail_offsets=(0, 1, 2, 3)):
+        from .dqn_engine import HID_SUPPORTED
+        from .mlp_engine import DQN_MLP_LAYERS
+        self.online = MlpWeights(model, DQN_MLP_LAYERS, with_grad=True, fp32_only=DQN_MLP_LAYERS, opt_chunk=256)
+        self.target = MlpWeights(target_model, DQN_MLP_LAYERS, with_grad=False, fp32_only=DQN_MLP_LAYERS,
+                                 opt_chunk=256)
+        on = self.online
+        dev = on.flat.device
+        self.HID, self.D, _ = on.shape["critic.0"]
+        self.A = on.shape["critic.6"][0]
+        if self.HID not in HID_SUPPORTED or self.A > 32 or self.HID % 4:
+            raise ValueError("unsupported dqn-mlp head shape")
+        self._init_common(batch_size, dev, per, seed, tail_offsets, n_losses=1, per_sample_loss=True)
+        self.norm_val = float(model.norm_val)
+        self.double = bool(double)
+        self.target_update = target_update
+        self.groups = 3 if self.double else 2
+        B, H = self.B, self.HID
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.x0 = z(2 * B, _pad4(self.D))           # (the stage block writes rows b and B + b)
+        self.hd = z(B, 4)
+        self.h1 = [z(B, H) for _ in range(self.groups)]
+        self.h2 = [z(B, H) for _ in range(self.groups)]
+        self.h3pre = [z(B, H) for _ in range(self.groups)]
+        self.h3, self.dh3 = z(B, H), z(B, H)
+        self.dq_ld = max(16, (self.A + 7) // 8 * 8)
+        self.dq = z(B, self.dq_ld)
+        self.dh2, self.dh1 = z(B, H), z(B, H)
+        self.q = z(B, self.A)
+        self.grads = model.flat_grads
+        self.grads.zero_()
+        self.gw, self.gb = on.grad_views(self.grads)
+        self.adam = FlatAdam(on.flat, self.grads, on.table, lr=lr, weight_decay=weight_decay, clip=clip,
+                             shadow=on.shadow)
+        polyak_(self.target.flat, on.flat, 1.0, self.target.table, self.target.shadow)
+        self.fused = True
+        self._lists = {}
+        _L()
+        from . import dqn_engine
+        dqn_engine._L()
+
+    def bind_replay(self, *a, **k):
+        self._lists = {}
+        return super().bind_replay(*a, **k)
+
+    def make_staging(self, *a, **k):
+        self._lists = {}
+        return super().make_staging(*a, **k)
+
+    def _build(self, staged):
+        from .dqn_engine import _HeadArgs
+        B, H, D, A, on, tg = self.B, self.HID, self.D, self.A, self.online, self.target
+        s0, s1, tails, idx, tree = self._sources(staged)
+        oa, orw, og, ot = self.tail_offsets
+        ld_s, sc = int(s0.stride(0)), 1.0 / self.norm_val
+        nets = [on, tg] + ([on] if self.double else [])
+        srcs = [s0, s1] + ([s1] if self.double else [])
+        st = _StageArgs(s0=_p(s0), ld_s=ld_s, tails=_p(tails), tail_ld=int(tails.stride(0)), off_action=oa,
+                        idx=_p(idx), B=B, D=D, A=0, x0=_p(self.x0), ld_x0=self.x0.stride(0), cat=_p(self.x0),
+                        ld_cat=self.x0.stride(0), c1=0, hd=_p(self.hd), off_reward=orw, off_gamma=og, off_term=ot)
+        g = dict(x_ld=ld_s, gather=idx, gather_mod=B, act=ACT_RELU, scale=sc)
+        fwd1 = JobList([fwd_job(src, n.w32["critic.0"], n.b["critic.0"], self.h1[i], B, H, D, **g)
+                        for i, (n, src) in enumerate(zip(nets, srcs))],
+                       stage=st, stage_blocks=min(256, (B * (D + 3) + 255) // 256))
+        fwd2 = JobList([fwd_job(self.h1[i], n.w32["critic.2"], n.b["critic.2"], self.h2[i], B, H, H, act=ACT_RELU)
+                        for i, n in enumerate(nets)])
+        fwd3 = JobList([fwd_job(self.h2[i], n.w32["critic.4"], None, self.h3pre[i], B, H, H, act=ACT_NONE)
+                        for i, n in enumerate(nets)])
+        head = _HeadArgs(
+            h1pre_on0=_p(self.h3pre[0]), h1pre_tg1=_p(self.h3pre[1]),
+            h1pre_on1=_p(self.h3pre[2]) if self.double else 0,
+            b4_on=_p(on.b["critic.4"]), b4_tg=_p(tg.b["critic.4"]),
+            w5_on=_p(on.w32["critic.6"]), b5_on=_p(on.b["critic.6"]),
+            w5_tg=_p(tg.w32["critic.6"]), b5_tg=_p(tg.b["critic.6"]),
+            tails=_p(tails), tail_ld=int(tails.stride(0)), off_action=oa, off_reward=orw, off_gamma=og, off_term=ot,
+            idx=_p(idx), isw=_p(self.isw) if self.per is not None else 0,
+            h1_on0=0, dh1=0, dq=0, dq_ld=self.dq_ld,
+            q_out=_p(self.q), td_out=_p(self.td), loss_sum=_p(self.loss_acc),
+            leaf_sum=_p(tree.sum) if tree is not None else 0, leaf_min=_p(tree.min) if tree is not None else 0,
+            prio_eps=float(self.per["eps"]) if self.per else 0.0,
+            prio_alpha=float(self.per["alpha"]) if self.per else 1.0,
+            B=B, HID=H, A=A, rng_counter=_p(self.counter), opt_step=_p(self.adam.step_dev),
+            h1_f32=_p(self.h3), dh1_f32=_p(self.dh3), dq_f32=_p(self.dq))
+        w = on.w32
+        bwd1 = JobList([dgrad_job(self.dh3, w["critic.4"], self.h2[0], self.dh2, B, H, H, act=ACT_RELU)])
+        bwd2 = JobList([dgrad_job(self.dh2, w["critic.2"], self.h1[0], self.dh1, B, H, H, act=ACT_RELU)])
+        gw, gb = self.gw, self.gb
+        wgrad = JobList([wgrad_job(self.dq, self.h3, gw["critic.6"], gb["critic.6"], B, A, H),
+                         wgrad_job(self.dh3, self.h2[0], gw["critic.4"], gb["critic.4"], B, H, H),
+                         wgrad_job(self.dh2, self.h1[0], gw["critic.2"], gb["critic.2"], B, H, H),
+                         wgrad_job(self.dh1, self.x0, gw["critic.0"], gb["critic.0"], B, H, D, scale=sc)])
+        return {"fwd": [fwd1, fwd2, fwd3], "head": head, "bwd": [bwd1, bwd2], "wgrad": wgrad}
+
+    def _get_lists(self, staged):
+        key = bool(staged)
+        if key not in self._lists:
+            self._lists[key] = self._build(key)
+        return self._lists[key]
+
+    def fused_forward_backward(self, staged=False):
+        ls = self._get_lists(staged)
+        for jl in ls["fwd"]:
+            jl.run()
+        lib().pda_dqn_head(ctypes.byref(ls["head"]), _stream())
+        for jl in ls["bwd"]:
+            jl.run()
+        self._last_staged = bool(staged)
+
+    def wgrad_all(self):
+        self._get_lists(getattr(self, "_last_staged", False))["wgrad"].run()
+
+    def forward_head(self, staged=False):
+        self.fused_forward_backward(staged)
+
+    def backward(self, staged=False):
+        self.wgrad_all()
+
+    def fused_extras(self, staged):
+        x = AdamExtras()
+        if self.presamples(staged):
+            x.next_idx, x.next_w, x.next_B = _p(self.idx), _p(self.isw), self.B
+            x.size, x.seed, x.counter = _p(self.size_dev), self.seed, _p(self.counter)
+        return x
+
+    def presamples(self, staged):
+        return (not staged) and self.replay is not None and not (self.replay[3] is not None and self.per is not None)
+
+    def update(self, staged=False, tick=False, extras=None):
+        if extras is not None and extras.next_idx:
+            self.adam.step(tick=tick, extras=extras)
+        else:
+            self.adam.step(tick=tick)
+        if self.target_update < 1.0:
+            polyak_(self.target.flat, self.online.flat, float(self.target_update), self.target.table,
+                    self.target.shadow)
         self._finish_update(staged)
 
     def hard_target_update(self):

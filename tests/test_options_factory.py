@@ -82,3 +82,28 @@ def test_reference_import_paths():
     from core.single_processes.logs import GlobalLogs  # noqa: F401
     from core.memories.shared_memory import SharedMemory   # noqa: F401
     assert O2 is Options
+
+
+def test_engine_knobs_resolve_from_options_and_environment(monkeypatch):
+    """ops/knobs.py is the one place that reads PDA_<NAME> tuning variables: defaults < Options.engine_knobs < env."""
+    from pytorch_distributed_amd.ops.knobs import DEFAULTS, resolve
+    from pytorch_distributed_amd.utils.options import Options
+    for name in DEFAULTS:
+        monkeypatch.delenv("PDA_" + name.upper(), raising=False)
+    k = resolve()
+    assert k.as_dict() == DEFAULTS and k.dp_grad_dtype == "measure"
+    opt = Options(config=1, overrides={"engine_knobs.fc1_blocks": 128, "engine_knobs.dp_graph": "split"})
+    k = resolve(opt)
+    assert k.fc1_blocks == 128 and k.dp_graph == "split" and k.pair_blocks == DEFAULTS["pair_blocks"]
+    monkeypatch.setenv("PDA_FC1_BLOCKS", "64")
+    monkeypatch.setenv("PDA_DP_ALLREDUCE", "PEER")
+    k = resolve(opt)
+    assert k.fc1_blocks == 64 and k.dp_allreduce == "peer"
+    assert resolve(opt, fc1_blocks=32).fc1_blocks == 32
+    import pytest
+    with pytest.raises(ValueError):
+        resolve(Options(config=1, overrides={"engine_knobs.no_such_knob": 1}))
+    with pytest.raises(ValueError):
+        resolve(dp_graph="sideways")
+    with pytest.raises(ValueError):
+        resolve(wgrad_blocks=-1)
