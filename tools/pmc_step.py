@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--replay", type=int, default=8192)
     ap.add_argument("--per", action="store_true")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--graph", action="store_true",
+                    help="graph-replayed steps (five updates per hipGraph, as the learner runs them) instead of eager ones; "
+                         "--steps is then rounded up to whole replays after one eager step")
     a = ap.parse_args()
     import torch
     from pytorch_distributed_amd import ops
@@ -52,11 +55,13 @@ def main():
         per = {"eps": 1e-6, "alpha": 0.5, "beta": 0.4}
     eng = DqnCnnEngine(model, target, a.batch, per=per, precision=a.precision).bind_replay(s0, s1, tails, tree)
     eng.set_size(m)
-    prog = DqnStepProgram(eng, None, use_graph=False)
-    for _ in range(a.steps):
+    prog = DqnStepProgram(eng, None, use_graph=a.graph, graph_steps=5 if a.graph else 1)
+    steps = a.steps if not a.graph else 1 + 5 * ((a.steps + 4) // 5)
+    for _ in range(steps):
         prog.step()
     torch.cuda.synchronize()
-    print("pmc_step: %d steps of batch %d, loss %.5f" % (a.steps, a.batch, eng.mean_loss()), flush=True)
+    print("pmc_step: %d %s steps of batch %d, loss %.5f" % (steps, "graph-replayed" if a.graph else "eager", a.batch,
+                                                             eng.mean_loss()), flush=True)
 
 
 if __name__ == "__main__":

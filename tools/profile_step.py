@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--tag", default="step")
     ap.add_argument("--per", action="store_true")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--graph", action="store_true", help="profile graph-replayed steps (tools/pmc_step.py --graph)")
     a = ap.parse_args()
     out = os.path.join(ROOT, "gpurun_out", a.tag)      # text summaries and pass logs (merged back by gpurun)
     raw = os.path.join("/tmp", "pda_prof", a.tag)       # rocprofv3 databases: large, stay on the GPU box
@@ -67,7 +68,8 @@ def main():
     env_tmp = "/tmp"
     os.environ["TMPDIR"] = env_tmp
     target = [sys.executable, os.path.join(ROOT, "tools", "pmc_step.py"), "--batch", str(a.batch),
-              "--steps", str(a.steps), "--precision", a.precision] + (["--per"] if a.per else [])
+              "--steps", str(a.steps), "--precision", a.precision] + (["--per"] if a.per else []) + \
+        (["--graph"] if a.graph else [])
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from rocpd_summary import short
 
@@ -103,8 +105,8 @@ def main():
 
     path = os.path.join(ROOT, "profiles", "%s_counters.txt" % a.tag)
     with open(path, "w") as fh:
-        fh.write("# hardware counters of the native DQN learner step, batch %d, %d eager steps (tools/profile_step.py)\n"
-                 % (a.batch, a.steps))
+        fh.write("# hardware counters of the native DQN learner step, batch %d, %d %s steps (tools/profile_step.py)\n"
+                 % (a.batch, a.steps, "graph-replayed" if a.graph else "eager"))
         fh.write("# mfma_busy%% = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * kernel time * 2.4 GHz): the counter adds, over every\n"
                  "#   SIMD of the chip, the cycles its matrix pipe is busy (cross-check at the end: it reads 16.00 per\n"
                  "#   v_mfma_f32_16x16x32_bf16, which holds its pipe for 16 cycles); at the 2.4 GHz ceiling clock this is a LOWER\n"
