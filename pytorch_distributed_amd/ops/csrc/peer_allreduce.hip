@@ -30,6 +30,12 @@
 // stores, never on another workgroup of the same GPU.
 // Optional bf16 wire format: two bf16 per granule (converted while being stored: no conversion launches), summed in
 // fp32; the reducing rank rounds its own result through bf16 as well, so all ranks still hold identical gradients.
+// Packed fp32 wire format (wire 2): the plain fp32 wire spends half of every granule on the tag (8 bytes per element);
+// here a granule carries 48 payload bits and a 16-bit tag, so three fp32 values travel in two granules
+//   {p0, p1.lo16 | tag16 << 16}  {p2, p1.hi16 | tag16 << 16}
+// = 5.33 bytes per element, still exact fp32, still one 8-byte store unit per tag.  tag16 = 0x8000 | (epoch & 0x7fff):
+// never zero (a fresh region is all zeros), and since every granule of a region is rewritten by every call the only
+// other tag a reader can meet is the previous call's.
 #include "common.h"
 #include <cstring>
 #include <cstdlib>
@@ -62,10 +68,13 @@ struct PeerArArgs {
 
 namespace {
 
-// bytes of one slot (a slice's granules): 8 bytes per fp32 element, 8 bytes per two bf16 elements
-__host__ __device__ inline long par_slot_bytes(long slice, bool bf16) { return slice * (bf16 ? 4 : 8); }
-__host__ __device__ inline long par_region_bytes(long slice, int world, bool bf16) {
-    return (long)sizeof(PeerRegionHeader) + 2L * world * par_slot_bytes(slice, bf16);    // staging + result slots
+// bytes of one slot (a slice's granules): 8 bytes per fp32 element, 8 bytes per two bf16 elements, 16 bytes per three
+// packed fp32 elements (slice is then a multiple of 24)
+__host__ __device__ inline long par_slot_bytes(long slice, int wire) {
+    return wire == 1 ? slice * 4 : (wire == 2 ? slice / 3 * 16 : slice * 8);
+}
+__host__ __device__ inline long par_region_bytes(long slice, int world, int wire) {
+    return (long)sizeof(PeerRegionHeader) + 2L * world * par_slot_bytes(slice, wire);    // staging + result slots
 }
 
 __device__ __forceinline__ unsigned ld_sys(const unsigned* p) {
@@ -104,13 +113,47 @@ __device__ __forceinline__ void st_pair(__amdgpu_buffer_rsrc_t rsrc, unsigned of
 __device__ __forceinline__ u32x4 ld_pair(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 17);
 }
-__device__ __forceinline__ bool pair_ok(u32x4 v, unsigned tag) { return v.y == tag && v.w == tag; }
 
-// the wire format: 4 consecutive elements <-> NP granule pairs
-template <bool BF16> struct Wire;
-template <> struct Wire<false> {        // one fp32 per granule: 4 elements = 2 pairs = 32 bytes
-    static constexpr int NP = 2;
-    static constexpr int BYTES4 = 32;
+// EL consecutive elements from ordinary device memory / back: EL = 4 (16-byte aligned) or 6 (8-byte aligned)
+template <int EL>
+__device__ __forceinline__ void load_el(const float* base, long e, long n, float* f) {
+    if constexpr (EL == 4) {
+        load4(base, e, n, f);
+    } else {
+        if (e + EL - 1 < n) {
+#pragma unroll
+            for (int q = 0; q < EL; q += 2) {
+                const float2 v = *reinterpret_cast<const float2*>(base + e + q);
+                f[q] = v.x; f[q + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < EL; ++k) f[k] = (e + k < n) ? base[e + k] : 0.f;
+        }
+    }
+}
+template <int EL>
+__device__ __forceinline__ void store_el(float* base, long e, long n, const float* f) {
+    if constexpr (EL == 4) {
+        store4(base, e, n, f);
+    } else {
+        if (e + EL - 1 < n) {
+#pragma unroll
+            for (int q = 0; q < EL; q += 2) *reinterpret_cast<float2*>(base + e + q) = make_float2(f[q], f[q + 1]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < EL; ++k)
+                if (e + k < n) base[e + k] = f[k];
+        }
+    }
+}
+
+// the wire format: one work item = EL consecutive elements <-> NP granule pairs (16-byte accesses) = BYTES bytes
+template <int WIRE> struct Wire;
+template <> struct Wire<0> {            // one fp32 per granule: 4 elements = 2 pairs = 32 bytes
+    static constexpr int EL = 4, NP = 2, BYTES = 32;
+    __device__ static unsigned tag_of(unsigned epoch) { return epoch; }
+    __device__ static bool ok(u32x4 v, unsigned tag) { return v.y == tag && v.w == tag; }
     __device__ static void store(__amdgpu_buffer_rsrc_t r, unsigned off, const float* f, unsigned tag) {
         st_pair(r, off, __float_as_uint(f[0]), __float_as_uint(f[1]), tag);
         st_pair(r, off + 16, __float_as_uint(f[2]), __float_as_uint(f[3]), tag);
@@ -121,9 +164,10 @@ template <> struct Wire<false> {        // one fp32 per granule: 4 elements = 2 
     }
     __device__ static void round_trip(float*) {}
 };
-template <> struct Wire<true> {         // two bf16 per granule: 4 elements = 1 pair = 16 bytes
-    static constexpr int NP = 1;
-    static constexpr int BYTES4 = 16;
+template <> struct Wire<1> {            // two bf16 per granule: 4 elements = 1 pair = 16 bytes
+    static constexpr int EL = 4, NP = 1, BYTES = 16;
+    __device__ static unsigned tag_of(unsigned epoch) { return epoch; }
+    __device__ static bool ok(u32x4 v, unsigned tag) { return v.y == tag && v.w == tag; }
     __device__ static void store(__amdgpu_buffer_rsrc_t r, unsigned off, const float* f, unsigned tag) {
         st_pair(r, off, pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), tag);
     }
@@ -136,21 +180,45 @@ template <> struct Wire<true> {         // two bf16 per granule: 4 elements = 1 
         for (int k = 0; k < 4; ++k) f[k] = bf2f(f2bf(f[k]));
     }
 };
+template <> struct Wire<2> {            // three fp32 per granule pair (48 payload + 16 tag bits per granule): 6 elements = 32 bytes
+    static constexpr int EL = 6, NP = 2, BYTES = 32;  // (the same registers per work item as the plain wire: all workgroups stay resident)
+    __device__ static unsigned tag_of(unsigned epoch) { return 0x8000u | (epoch & 0x7fffu); }
+    __device__ static bool ok(u32x4 v, unsigned tag) { return (v.y >> 16) == tag && (v.w >> 16) == tag; }
+    __device__ static void store(__amdgpu_buffer_rsrc_t r, unsigned off, const float* f, unsigned tag) {
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            const unsigned p0 = __float_as_uint(f[3 * h]), p1 = __float_as_uint(f[3 * h + 1]), p2 = __float_as_uint(f[3 * h + 2]);
+            u32x4 v = {p0, (p1 & 0xffffu) | (tag << 16), p2, (p1 >> 16) | (tag << 16)};
+            __builtin_amdgcn_raw_buffer_store_b128(v, r, off + 16 * h, 0, 17);
+        }
+    }
+    __device__ static void unpack(const u32x4* v, float* f) {
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            f[3 * h] = __uint_as_float(v[h].x);
+            f[3 * h + 1] = __uint_as_float((v[h].y & 0xffffu) | (v[h].w << 16));
+            f[3 * h + 2] = __uint_as_float(v[h].z);
+        }
+    }
+    __device__ static void round_trip(float*) {}
+};
 
-template <bool BF16>
+template <int WIRE>
 __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs a) {
-    typedef Wire<BF16> W;
+    typedef Wire<WIRE> W;
+    constexpr int EL = W::EL;
     const int p = blockIdx.x / a.chunks, j = blockIdx.x % a.chunks;       // (peer, chunk of that peer's slice)
     const int r = a.rank, world = a.world;
     PeerRegionHeader* me = reinterpret_cast<PeerRegionHeader*>(a.region[r]);
     const unsigned epoch = ld_sys(&me->epoch) + 1u;         // every workgroup reads it before any can finish the call
+    const unsigned tag = W::tag_of(epoch);
     // (both hooks live in device memory, not in the launch arguments: a captured launch replays them as they are NOW)
     const bool withhold = ld_sys(&me->fault) != 0u;
     const unsigned lim = ld_sys(&me->spin_limit);
     const unsigned spin_limit = lim ? lim : PAR_SPIN_LIMIT;
     const long slice = a.slice, chunk = a.chunk;
     const long c0 = (long)j * chunk, c1 = min(c0 + chunk, slice);          // chunk range within a slice
-    const unsigned slot = (unsigned)par_slot_bytes(slice, BF16);
+    const unsigned slot = (unsigned)par_slot_bytes(slice, WIRE);
     const unsigned hdr = (unsigned)sizeof(PeerRegionHeader);
     // region of rank `owner`: staging slot s at hdr + s * slot, result slot s at hdr + (world + s) * slot
     auto rsrc_of = [&](int owner) {
@@ -162,19 +230,19 @@ __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs 
     if (p != r && !withhold) {
         const __amdgpu_buffer_rsrc_t dst = rsrc_of(p);
         const unsigned base = hdr + (unsigned)r * slot;
-        for (long e = c0 + (long)threadIdx.x * 4; e < c1; e += (long)PAR_THREADS * 4) {
-            float f[4];
-            load4(a.local, (long)p * slice + e, a.n, f);
-            W::store(dst, base + (unsigned)(e / 4) * W::BYTES4, f, epoch);
+        for (long e = c0 + (long)threadIdx.x * EL; e < c1; e += (long)PAR_THREADS * EL) {
+            float f[EL];
+            load_el<EL>(a.local, (long)p * slice + e, a.n, f);
+            W::store(dst, base + (unsigned)(e / EL) * W::BYTES, f, tag);
         }
     }
 
     // ---- phase 2: reduce sub-chunk p of chunk j of MY slice; into my gradient and every peer's result slot r ----
     {
-        const long sub = chunk / world;                     // multiple of 8 (pda_peer_plan)
+        const long sub = chunk / world;                     // multiple of 8 / 24 (pda_peer_plan3)
         const long s0 = min(c0 + (long)p * sub, c1), s1 = (p == world - 1) ? c1 : min(s0 + sub, c1);
-        for (long e = s0 + (long)threadIdx.x * 4; e < s1; e += (long)PAR_THREADS * 4) {
-            const unsigned goff = (unsigned)(e / 4) * W::BYTES4;
+        for (long e = s0 + (long)threadIdx.x * EL; e < s1; e += (long)PAR_THREADS * EL) {
+            const unsigned goff = (unsigned)(e / EL) * W::BYTES;
             // all peers' granules in flight together, then re-poll whatever has not arrived
             u32x4 v[PAR_MAX_RANKS][W::NP];
 #pragma unroll
@@ -190,7 +258,7 @@ __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs 
                     if (s < world && s != r) {
 #pragma unroll
                         for (int h = 0; h < W::NP; ++h)
-                            if (!pair_ok(v[s][h], epoch)) {
+                            if (!W::ok(v[s][h], tag)) {
                                 all_ok = false;
                                 v[s][h] = ld_pair(mine, hdr + (unsigned)s * slot + goff + 16 * h);
                             }
@@ -199,34 +267,36 @@ __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs 
                 __builtin_amdgcn_s_sleep(4);
                 if (++spins > spin_limit) { atomicExch(&me->error, (1u << 8) | 0xffu); break; }
             }
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            float acc[EL];
+#pragma unroll
+            for (int k = 0; k < EL; ++k) acc[k] = 0.f;
 #pragma unroll
             for (int s = 0; s < PAR_MAX_RANKS; ++s)             // rank order: the same sum on every run and rank
                 if (s < world) {
-                    float f[4];
+                    float f[EL];
                     if (s == r) {
-                        load4(a.local, (long)r * slice + e, a.n, f);
+                        load_el<EL>(a.local, (long)r * slice + e, a.n, f);
                         W::round_trip(f);
                     } else {
                         W::unpack(v[s], f);
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[k] += f[k];
+                    for (int k = 0; k < EL; ++k) acc[k] += f[k];
                 }
             W::round_trip(acc);                                 // every rank ends up with the same bits
-            store4(a.local, (long)r * slice + e, a.n, acc);
+            store_el<EL>(a.local, (long)r * slice + e, a.n, acc);
 #pragma unroll
             for (int q = 0; q < PAR_MAX_RANKS; ++q)
                 if (q < world && q != r)
-                    W::store(rsrc_of(q), hdr + (unsigned)(world + r) * slot + goff, acc, epoch);
+                    W::store(rsrc_of(q), hdr + (unsigned)(world + r) * slot + goff, acc, tag);
         }
     }
 
     // ---- phase 3: reduced chunk j of peer p's slice -> my gradient buffer ----------------------------------------
     if (p != r) {
         const unsigned base = hdr + (unsigned)(world + p) * slot;
-        for (long e = c0 + (long)threadIdx.x * 4; e < c1; e += (long)PAR_THREADS * 4) {
-            const unsigned goff = base + (unsigned)(e / 4) * W::BYTES4;
+        for (long e = c0 + (long)threadIdx.x * EL; e < c1; e += (long)PAR_THREADS * EL) {
+            const unsigned goff = base + (unsigned)(e / EL) * W::BYTES;
             u32x4 v[W::NP];
 #pragma unroll
             for (int h = 0; h < W::NP; ++h) v[h] = ld_pair(mine, goff + 16 * h);
@@ -234,14 +304,14 @@ __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs 
                 bool all_ok = true;
 #pragma unroll
                 for (int h = 0; h < W::NP; ++h)
-                    if (!pair_ok(v[h], epoch)) { all_ok = false; v[h] = ld_pair(mine, goff + 16 * h); }
+                    if (!W::ok(v[h], tag)) { all_ok = false; v[h] = ld_pair(mine, goff + 16 * h); }
                 if (all_ok) break;
                 __builtin_amdgcn_s_sleep(4);
                 if (++spins > spin_limit) { atomicExch(&me->error, (2u << 8) | (unsigned)p); break; }
             }
-            float f[4];
+            float f[EL];
             W::unpack(v, f);
-            store4(a.local, (long)p * slice + e, a.n, f);
+            store_el<EL>(a.local, (long)p * slice + e, a.n, f);
         }
     }
 
@@ -264,29 +334,34 @@ __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs 
 // budget: workgroups of the launch as a whole (0 = 224, all resident on a GPU of its own; several ranks SHARING one
 // card -- rehearsals on a one-GPU box -- must fit all their launches on it together and ask for fewer).  Every rank
 // must use the same budget: the chunk geometry addresses the peers' regions.
-PDA_EXPORT void pda_peer_plan2(long n, int world, int budget, long* slice, long* chunk, int* chunks) {
+PDA_EXPORT void pda_peer_plan3(long n, int world, int budget, int wire, long* slice, long* chunk, int* chunks) {
+    const long unit = wire == 2 ? 24 : 8;           // whole 16-byte accesses of every wire format (packed fp32: 6-element items)
     long sl = (n + world - 1) / world;
-    sl = (sl + 7) / 8 * 8;
+    sl = (sl + unit - 1) / unit * unit;
     if (budget <= 0) budget = 224;
     int target = budget / world;                    // ~224 resident workgroups in all
     if (target > PAR_MAX_CHUNKS) target = PAR_MAX_CHUNKS;
     if (target < 1) target = 1;
-    const long gran = 8L * world;                   // sub-chunks stay whole 16-byte accesses
+    const long gran = unit * world;                 // sub-chunks stay whole work items
     long ch = (sl + target - 1) / target;
     ch = (ch + gran - 1) / gran * gran;
     if (ch < gran) ch = gran;
     int nch = (int)((sl + ch - 1) / ch);
     *slice = sl; *chunk = ch; *chunks = nch;
 }
-
-PDA_EXPORT void pda_peer_plan(long n, int world, long* slice, long* chunk, int* chunks) {
-    pda_peer_plan2(n, world, 0, slice, chunk, chunks);
+PDA_EXPORT void pda_peer_plan2(long n, int world, int budget, long* slice, long* chunk, int* chunks) {
+    pda_peer_plan3(n, world, budget, 0, slice, chunk, chunks);
 }
 
-PDA_EXPORT long pda_peer_region_bytes(long n, int world, int wire_bf16) {
+PDA_EXPORT void pda_peer_plan(long n, int world, long* slice, long* chunk, int* chunks) {
+    pda_peer_plan3(n, world, 0, 0, slice, chunk, chunks);
+}
+
+// wire: 0 = fp32 (8 bytes per element), 1 = bf16 (4), 2 = packed fp32 (5.33)
+PDA_EXPORT long pda_peer_region_bytes(long n, int world, int wire) {
     long slice, chunk; int chunks;
-    pda_peer_plan(n, world, &slice, &chunk, &chunks);
-    return par_region_bytes(slice, world, wire_bf16 != 0);
+    pda_peer_plan3(n, world, 0, wire, &slice, &chunk, &chunks);
+    return par_region_bytes(slice, world, wire);
 }
 
 // Uncached device memory, zero-filled, + its IPC handle (64 bytes).  Returns 0 on success, a hipError_t otherwise.
@@ -339,17 +414,18 @@ PDA_EXPORT int pda_peer_set_fault(void* region, unsigned withhold, unsigned spin
     return (int)hipMemcpy((char*)region + offsetof(PeerRegionHeader, fault), v, sizeof(v), hipMemcpyHostToDevice);
 }
 
-PDA_EXPORT int pda_peer_allreduce(void* const* regions, void* local, long n, int rank, int world, int wire_bf16,
+PDA_EXPORT int pda_peer_allreduce(void* const* regions, void* local, long n, int rank, int world, int wire,
                                   int budget, hipStream_t stream) {
-    if (world < 2 || world > PAR_MAX_RANKS) return -1;
+    if (world < 2 || world > PAR_MAX_RANKS || wire < 0 || wire > 2) return -1;
     PeerArArgs a;
     for (int i = 0; i < PAR_MAX_RANKS; ++i) a.region[i] = i < world ? (char*)regions[i] : nullptr;
     a.local = (float*)local; a.n = n; a.rank = rank; a.world = world;
-    pda_peer_plan2(n, world, budget, &a.slice, &a.chunk, &a.chunks);
-    a.region_bytes = par_region_bytes(a.slice, world, wire_bf16 != 0);
+    pda_peer_plan3(n, world, budget, wire, &a.slice, &a.chunk, &a.chunks);
+    a.region_bytes = par_region_bytes(a.slice, world, wire);
     if (a.region_bytes >= (1L << 31)) return -2;            // buffer descriptors address 2 GB
     dim3 grid(world * a.chunks), block(PAR_THREADS);
-    if (wire_bf16) hipLaunchKernelGGL(peer_allreduce_kernel<true>, grid, block, 0, stream, a);
-    else hipLaunchKernelGGL(peer_allreduce_kernel<false>, grid, block, 0, stream, a);
+    if (wire == 1) hipLaunchKernelGGL(peer_allreduce_kernel<1>, grid, block, 0, stream, a);
+    else if (wire == 2) hipLaunchKernelGGL(peer_allreduce_kernel<2>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(peer_allreduce_kernel<0>, grid, block, 0, stream, a);
     return (int)hipGetLastError();
 }

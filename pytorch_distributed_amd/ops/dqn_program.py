@@ -83,7 +83,8 @@ class DqnStepProgram(object):
                 kind = "rccl"           # FakeComm / CPU tensors: the communicator's own reduce
             self.comm_report, self._spare_allreduces = {"us": {}, "chosen": None}, []
             if knobs.dp_grad_dtype == "measure" and kind != "rccl":
-                wires = ("fp32",) if e.x3 else ("fp32", "bf16")
+                # (exact fp32 wires for the fp32-class engine: plain and packed; the bf16 engine may also round the wire)
+                wires = ("fp32", "fp32p") if e.x3 else ("fp32", "fp32p", "bf16")
                 self.ar_tail, self.comm_report, self._spare_allreduces = choose_grad_allreduce(
                     comm, self.tail, kind, wires, wg)
                 head_kind = "rccl" if self.ar_tail.kind == "rccl" else kind

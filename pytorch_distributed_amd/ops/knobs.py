@@ -31,8 +31,9 @@ DEFAULTS = {
     # how the step is captured (auto | whole | split; bench.py / the learner set it from parallel/preflight.py), and
     # the peer kernel's workgroup budget (0 = its own plan; shared-card rehearsals of 8 ranks need <= 64).
     # "measure": the candidates are TIMED on the real fc-tail bucket when the step program is built -- the peer kernel
-    # with an fp32 wire, with a bf16 wire (bf16 engines only: the fp32-class engine keeps exact fp32 sums) and, with
-    # dp_allreduce=auto on an RCCL group, the process group's all-reduce -- and the fastest is used
+    # with the plain fp32 wire (8 bytes per element), the packed fp32 wire (5.33 bytes, still exact), a bf16 wire
+    # (bf16 engines only: the fp32-class engine keeps exact fp32 sums) and, with dp_allreduce=auto on an RCCL group,
+    # the process group's all-reduce -- and the fastest is used
     # (parallel/peer_allreduce.py:choose_grad_allreduce; the timings go into bench.py's JSON as "dp_wire_choice").
     "dp_grad_dtype": "measure",
     "dp_allreduce": "auto",

@@ -41,6 +41,10 @@ def _lib():
         L.pda_peer_plan2.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_long),
                                      ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_int)]
         L.pda_peer_plan2.restype = None
+        L.pda_peer_plan3.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long),
+                                     ctypes.POINTER(ctypes.c_int)]
+        L.pda_peer_plan3.restype = None
         L.pda_peer_region_bytes.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int]
         L.pda_peer_region_bytes.restype = ctypes.c_long
         L.pda_peer_alloc.argtypes = [ctypes.c_long, ctypes.c_uint, ctypes.POINTER(_vp), ctypes.c_char_p]
@@ -64,11 +68,18 @@ def _lib():
     return L
 
 
-def plan(numel, world, budget=0):
+# wire formats of the hand-off granules (csrc/peer_allreduce.hip): bytes per gradient element on the links
+WIRES = {"fp32": 0,     # one fp32 + a 32-bit tag per 8-byte granule: 8 bytes per element
+         "bf16": 1,     # two bf16 + tag: 4 bytes per element, sums rounded through bf16
+         "fp32p": 2}    # packed: three fp32 per two granules (48 payload + 16 tag bits each): 5.33 bytes, exact
+
+
+def plan(numel, world, budget=0, wire="fp32"):
     """(slice, chunk, chunks per slice) the kernel uses for `numel` elements over `world` ranks."""
     L = _lib()
     sl, ch, n = ctypes.c_long(), ctypes.c_long(), ctypes.c_int()
-    L.pda_peer_plan2(int(numel), int(world), int(budget), ctypes.byref(sl), ctypes.byref(ch), ctypes.byref(n))
+    L.pda_peer_plan3(int(numel), int(world), int(budget), WIRES[wire], ctypes.byref(sl), ctypes.byref(ch),
+                     ctypes.byref(n))
     return sl.value, ch.value, n.value
 
 
@@ -87,21 +98,23 @@ _regions_created = 0        # per process; every rank creates its regions in the
 
 class PeerAllReduce(object):
     """In-place SUM all-reduce of ONE fixed fp32 device buffer of `numel` elements over the ranks of `comm`
-    (a TorchComm: used only to exchange the 64-byte IPC handles).  wire="bf16" sends slices as bf16."""
+    (a TorchComm: used only to exchange the 64-byte IPC handles).  wire: see WIRES ("bf16" sends slices as bf16,
+    "fp32p" packs three exact fp32 values into 16 bytes instead of two)."""
 
     def __init__(self, comm, numel, device, wire="fp32", workgroups=None):
         self.comm, self.numel, self.device = comm, int(numel), torch.device(device)
         self.rank, self.world = int(comm.rank), int(comm.world_size)
         if not 2 <= self.world <= MAX_RANKS:
             raise ValueError("peer all-reduce serves 2..%d ranks, not %d" % (MAX_RANKS, self.world))
-        if wire not in ("fp32", "bf16"):
-            raise ValueError("wire must be 'fp32' or 'bf16'")
+        if wire not in WIRES:
+            raise ValueError("wire must be one of %s" % "|".join(sorted(WIRES)))
+        self.wire, self.wire_code = wire, WIRES[wire]
         self.wire_bf16 = 1 if wire == "bf16" else 0
         self.budget = workgroup_budget(workgroups)
         self.local, self.peers, self.closed = None, {}, False
         L = _lib()
         torch.cuda.set_device(self.device)
-        nbytes = L.pda_peer_region_bytes(self.numel, self.world, self.wire_bf16)
+        nbytes = L.pda_peer_region_bytes(self.numel, self.world, self.wire_code)
         ptr, handle = _vp(), ctypes.create_string_buffer(64)
         global _regions_created
         _regions_created += 1
@@ -148,7 +161,7 @@ class PeerAllReduce(object):
         assert flat.dtype == torch.float32 and flat.is_contiguous() and flat.numel() == self.numel
         assert flat.data_ptr() % 16 == 0, "gradient bucket must start on a 16-byte boundary"
         rc = _lib().pda_peer_allreduce(self.regions, _vp(flat.data_ptr()), self.numel, self.rank, self.world,
-                                       self.wire_bf16, self.budget, _vp(torch.cuda.current_stream().cuda_stream))
+                                       self.wire_code, self.budget, _vp(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise RuntimeError("peer all-reduce launch failed: hipError %d" % rc)
         return flat
@@ -323,7 +336,8 @@ def _worker():
                      backend=backend, timeout_s=120)
     out = {"rank": rank, "world": world, "cases": []}
     ok_all = True
-    for numel, wire in ((1000, "fp32"), (77984, "fp32"), (1609222, "fp32"), (1687206, "fp32"), (1609222, "bf16")):
+    for numel, wire in ((1000, "fp32"), (77984, "fp32"), (1609222, "fp32"), (1687206, "fp32"), (1609222, "bf16"),
+                        (1000, "fp32p"), (77984, "fp32p"), (1609222, "fp32p")):
         peer = PeerAllReduce(comm, numel, dev, wire=wire)
         g = torch.Generator(device=dev).manual_seed(1234 + 17 * rank)
         x = torch.randn(numel, device=dev, generator=g)
@@ -342,7 +356,7 @@ def _worker():
         peer.all_reduce_sum_(got)
         torch.cuda.synchronize(dev)
         untouched = bool(torch.equal(x.cpu(), mine) and (guard_lo == 7.0).all() and (guard_hi == 7.0).all())
-        tol = 0.0 if wire == "fp32" else 2e-2 * float(ref.abs().max().item())
+        tol = 0.0 if wire != "bf16" else 2e-2 * float(ref.abs().max().item())
         err = float((got - ref).abs().max().item())
         # every rank must hold the SAME bits: compare with rank 0's result
         r0 = got.clone()
@@ -374,7 +388,7 @@ def _worker():
         graphed = bool(torch.equal(y, got))
         case = {"numel": numel, "wire": wire, "max_err_vs_group_sum": err, "tol": tol, "same_bits_on_all_ranks": same,
                 "chained_calls_ok": chained, "graph_replay_ok": graphed, "us_per_call_in_graph": round(1e6 * dt, 1),
-                "kernel_error_word": peer.error(), "plan": plan(numel, world, peer.budget)}
+                "kernel_error_word": peer.error(), "plan": plan(numel, world, peer.budget, wire)}
         if err > tol:       # where, and what the two sums and this rank's own contribution are there
             bad = ((got - ref).abs() > tol).nonzero().reshape(-1)
             case["bad_count"] = int(bad.numel())

@@ -60,11 +60,13 @@ def test_two_rank_dp_with_the_peer_allreduce_in_one_graph(precision):
     # dp_grad_dtype=measure): the fp32-class engine only considers the exact fp32 wire
     choice = res["dp_wire_choice"]
     assert res["dp_allreduce"] == choice["chosen"] and res["dp_graph"] == "whole"
+    exact = {"peer-fp32", "peer-fp32p"}         # plain and packed fp32 wires: both carry exact fp32 sums
     if precision == "fp32":
-        assert res["dp_allreduce"] == "peer-fp32" and res["dp_grad_allreduce_dtype"] == "fp32"
+        assert set(choice["us"]) == exact and res["dp_grad_allreduce_dtype"] == "fp32"
     else:
-        assert set(choice["us"]) == {"peer-fp32", "peer-bf16"} and all(v > 0 for v in choice["us"].values())
-        assert res["dp_allreduce"] == min(choice["us"], key=choice["us"].get)
+        assert set(choice["us"]) == exact | {"peer-bf16"}
+    assert all(v > 0 for v in choice["us"].values())
+    assert res["dp_allreduce"] == min(sorted(choice["us"]), key=choice["us"].get)
     # ... and the step reports where its communication goes
     cu = res["dp_comm_us"]
     assert cu["steps"] == 20 and cu["allreduce_tail_us"] > 0 and cu["allreduce_head_us"] > 0
@@ -93,7 +95,7 @@ def test_eight_rank_dp_step_on_one_card():
     assert out.returncode == 0, out.stderr.decode(errors="replace")[-2000:]
     res = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][0])
     assert res["n_gpus"] == 8 and res["config"]["global_batch"] == 8 * 128
-    assert res["dp_allreduce"] in ("peer-fp32", "peer-bf16") and res["dp_graph"] == "whole"
+    assert res["dp_allreduce"] in ("peer-fp32", "peer-fp32p", "peer-bf16") and res["dp_graph"] == "whole"
     assert res["dp_wire_choice"]["chosen"] == res["dp_allreduce"]
     assert res["dp_param_max_abs_diff_across_ranks"] == 0.0 and res["dp_allreduce_errors"] == 0
     assert res["rccl_ranks"] == 8 and res["ranks_distinct"] is True and res["rank_id_min_max_sum"] == [0, 7, 28]
