@@ -266,6 +266,8 @@ __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs 
                 if (all_ok) break;
                 __builtin_amdgcn_s_sleep(4);
                 if (++spins > spin_limit) { atomicExch(&me->error, (1u << 8) | 0xffu); break; }
+                // a wait of this call has already run out somewhere on this GPU: the result is void anyway, drain fast
+                if ((spins & 63u) == 0u && ld_sys(&me->error) != 0u) break;
             }
             float acc[EL];
 #pragma unroll
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs 
                 if (all_ok) break;
                 __builtin_amdgcn_s_sleep(4);
                 if (++spins > spin_limit) { atomicExch(&me->error, (2u << 8) | (unsigned)p); break; }
+                if ((spins & 63u) == 0u && ld_sys(&me->error) != 0u) break;
             }
             float f[EL];
             W::unpack(v, f);

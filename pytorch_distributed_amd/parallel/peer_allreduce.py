@@ -225,6 +225,10 @@ def self_test(peer, comm, device):
     """One real all-reduce of rank-dependent values through `peer`, checked on every rank; all ranks agree
     on the verdict.  The kernel's waits are bounded, so a broken mapping fails here instead of hanging."""
     n = peer.numel
+    # the ranks enter together and the waits are short (~50 ms): a mapping that does not deliver fails in about a
+    # second per rank instead of after the kernel's default (a second per wait)
+    comm.barrier()
+    peer.set_fault(False, spin_limit=1 << 17)
     buf = torch.arange(n, device=device, dtype=torch.float32).remainder_(97.0).add_(float(peer.rank + 1))
     want = torch.arange(n, device=device, dtype=torch.float32).remainder_(97.0).mul_(float(peer.world)) \
         .add_(float(peer.world * (peer.world + 1) // 2))
@@ -234,6 +238,7 @@ def self_test(peer, comm, device):
     torch.cuda.synchronize(device)
     tol = 0.0 if not peer.wire_bf16 else 0.02 * float(want.abs().max().item())
     ok = peer.error() == 0 and float((buf - want).abs().max().item()) <= tol
+    peer.set_fault(False, spin_limit=0)         # back to the default limit
     return comm.all_agree(ok)
 
 
