@@ -49,14 +49,20 @@ __global__ __launch_bounds__(256) void segtree_sample_kernel(const float* __rest
                                                              const float* __restrict__ mn, TreeOffsets offs,
                                                              int depth, int num_leaves,
                                                              const float* __restrict__ uniforms, int B, float beta,
-                                                             int* __restrict__ out_idx, float* __restrict__ out_w) {
+                                                             int* __restrict__ out_idx, float* __restrict__ out_w,
+                                                             unsigned long long seed,
+                                                             const unsigned long long* __restrict__ counter) {
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= B) return;
     int top = offs.off[depth - 1];
     float kid = sum[top + lane];
+    // uniforms == nullptr: the stratum's uniform is drawn here (the same counter hash as uniform_f32_kernel: one launch
+    // less per prioritized step)
+    const float u = uniforms ? uniforms[wave]
+                             : u01(hash_u32(seed ^ (*counter * 0x9e3779b97f4a7c15ULL + (unsigned long long)wave + 1)));
     float total = wave_sum(kid);
     float pmin = wave_min(mn[top + lane]);
-    float v = ((float)wave + uniforms[wave]) / (float)B * total;
+    float v = ((float)wave + u) / (float)B * total;
     int node = 0;
     for (int lvl = depth - 1; lvl >= 0; --lvl) {
         if (lvl != depth - 1) kid = sum[(long)offs.off[lvl] + (long)node * RADIX + lane];
@@ -92,7 +98,18 @@ PDA_EXPORT void pda_segtree_sample(const void* sum, const void* mn, const int* o
     long threads = (long)B * 64;
     hipLaunchKernelGGL(segtree_sample_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
                        (const float*)sum, (const float*)mn, o, depth, num_leaves, (const float*)uniforms, B, beta,
-                       (int*)out_idx, (float*)out_w);
+                       (int*)out_idx, (float*)out_w, 0ull, (const unsigned long long*)nullptr);
+}
+// the same draw with the uniforms generated in the kernel from (seed, *counter): see uniform_f32_kernel
+PDA_EXPORT void pda_segtree_sample_rng(const void* sum, const void* mn, const int* offs, int depth, int num_leaves,
+                                       int B, float beta, void* out_idx, void* out_w, unsigned long long seed,
+                                       const void* counter, hipStream_t stream) {
+    TreeOffsets o;
+    for (int i = 0; i < 8; ++i) o.off[i] = offs[i];
+    long threads = (long)B * 64;
+    hipLaunchKernelGGL(segtree_sample_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)sum, (const float*)mn, o, depth, num_leaves, (const float*)nullptr, B, beta,
+                       (int*)out_idx, (float*)out_w, seed, (const unsigned long long*)counter);
 }
 
 // uniform index draw on device (counter-based, graph-replayable: the counter lives in memory)

@@ -184,8 +184,11 @@ class DqnCnnEngine(object):
         s0, s1, tails, tree = self.replay
         L = _L()
         if tree is not None and self.per is not None:
-            L.pda_uniform_f32(_p(self.uniforms), self.B, self.seed, _p(self.counter), _stream())
-            tree.sample(self.uniforms, float(self.per["beta"]), self.idx, self.isw)
+            if getattr(tree, "native", False):      # stratum uniforms drawn inside the descent kernel: one launch
+                tree.sample_rng(self.B, float(self.per["beta"]), self.seed, self.counter, self.idx, self.isw)
+            else:
+                L.pda_uniform_f32(_p(self.uniforms), self.B, self.seed, _p(self.counter), _stream())
+                tree.sample(self.uniforms, float(self.per["beta"]), self.idx, self.isw)
         else:
             L.pda_uniform_idx(_p(self.idx), _p(self.isw), self.B, _p(self.size_dev), self.seed, _p(self.counter),
                               _stream())

@@ -105,6 +105,21 @@ class DeviceSumMinTree(object):
     def get(self, leaf_inds):
         return self.sum[leaf_inds.long()]
 
+    def sample_rng(self, B, beta, seed, counter, out_idx, out_weight):
+        """sample() with the B stratum uniforms drawn inside the kernel from (seed, *counter) -- the counter hash of
+        pda_uniform_f32, so the draw equals sample(pda_uniform_f32(...)) -- native only, one launch."""
+        assert self.native
+        L = lib()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        offs = (ctypes.c_int * 8)(*([int(o) for o in self.offsets] + [0] * (8 - self.depth)))
+        L.pda_segtree_sample_rng.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p]
+        L.pda_segtree_sample_rng.restype = None
+        L.pda_segtree_sample_rng(_p(self.sum), _p(self.min), offs, self.depth, self.num_leaves, int(B),
+                                 ctypes.c_float(beta), _p(out_idx), _p(out_weight), int(seed), _p(counter), _s(stream))
+        return out_idx, out_weight
+
     def sample(self, uniforms, beta, out_idx=None, out_weight=None):
         """Stratified draw: sample i targets mass (i + uniforms[i]) / B * total.
         Returns (idx int32 (B,), importance weight fp32 (B,) = (p_min/p_i)^beta)."""

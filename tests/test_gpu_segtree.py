@@ -85,3 +85,30 @@ def test_two_million_leaves_depth_and_distribution(tree_cls):
     tree.update(some, newv)
     prio[some.long()] = 5.0
     assert abs(float(tree.total()) - float(prio.double().sum())) < 1e-4 * float(prio.double().sum())
+
+
+@pytest.mark.gpu
+def test_sample_rng_equals_sample_of_the_same_counter_hash():
+    """The prioritized step draws its stratum uniforms inside the descent kernel (sample_rng): the same indices and
+    weights as uniform_f32 + sample, one launch less."""
+    import ctypes
+    from pytorch_distributed_amd.ops import lib
+    from pytorch_distributed_amd.ops.segtree import DeviceSumMinTree
+    dev = torch.device("cuda:0")
+    n, B = 50000, 128
+    tree = DeviceSumMinTree(n, dev)
+    tree.update(torch.arange(n, device=dev, dtype=torch.int32), torch.rand(n, device=dev) + 0.05)
+    counter = torch.tensor([7], dtype=torch.int64, device=dev)
+    seed = 0x1234567
+    L = lib()
+    L.pda_uniform_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p]
+    L.pda_uniform_f32.restype = None
+    u = torch.zeros(B, device=dev)
+    L.pda_uniform_f32(u.data_ptr(), B, seed, counter.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    i0, w0 = tree.sample(u, 0.4)
+    i1 = torch.zeros(B, dtype=torch.int32, device=dev)
+    w1 = torch.zeros(B, device=dev)
+    tree.sample_rng(B, 0.4, seed, counter, i1, w1)
+    torch.cuda.synchronize()
+    assert torch.equal(i0, i1) and torch.equal(w0, w1)
+    assert (u > 0).all() and (u < 1).all() and i1.unique().numel() > B // 2
