@@ -51,6 +51,9 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=128, help="transitions per GPU per step")
     ap.add_argument("--replay", type=int, default=50000)
     ap.add_argument("--config", type=int, default=2, help="options.CONFIGS row (2 uniform, 4 Ape-X PER)")
+    ap.add_argument("--memory-type", default=None,
+                    help="replay kind override, e.g. device-dedup / device-dedup-per (frame-deduplicated HBM replay: "
+                         "every frame stored once, memories/dedup_memory.py)")
     ap.add_argument("--compute", default="native", choices=["native", "torch"])
     ap.add_argument("--precision", default="both", choices=["both", "fp32", "bf16"],
                     help="native engine arithmetic: fp32 = split-bf16 x3 products (fp32-equivalent, the headline), "
@@ -313,6 +316,7 @@ def run_rank(a):
 
     def options(precision):
         opt = prepare_options(Options(config=a.config, overrides={
+            **({"memory_type": a.memory_type} if a.memory_type else {}),
             "device": "cuda" if use_cuda else "cpu", "compute": a.compute, "num_learners": world,
             "force_dp": a.force_dp, "precision": precision,
             "memory_params.replay_device": "cuda" if use_cuda else "cpu",
@@ -333,6 +337,11 @@ def run_rank(a):
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     gamma_n = ap_.gamma ** ap_.nstep
     filled = 0
+    if getattr(memory, "dedup", False):     # frame-deduplicated replay: one random plane per step, as the actors' runs
+        memory.fill_synthetic(memory.memory_size, nstep=ap_.nstep, seed=1000 + rank, num_actions=opt.action_space,
+                              gamma_n=gamma_n)
+        filled = memory.memory_size
+        s = None
     while filled < memory.memory_size:      # synthetic transitions, written straight into the replay
         n = min(4096, memory.memory_size - filled)
         s = torch.randint(0, 256, (n + 1,) + tuple(opt.state_shape), dtype=torch.uint8, device=device, generator=gen)
@@ -454,7 +463,8 @@ def run_rank(a):
             "samples_per_sec": round(ups * a.batch, 1), "final_loss": round(float(results[head]["loss"]), 6),
             "config": {"model": "dqn-cnn (Nature CNN, 6 actions, 1,687,206 params)", "global_batch": a.batch * world,
                        "seq_len": None, "obs": "4x84x84 uint8", "nstep": ap_.nstep, "replay": a.replay,
-                       "replay_kind": "prioritized (HIP sum/min tree)" if memory.enable_per else "uniform",
+                       "replay_kind": ("prioritized (HIP sum/min tree)" if memory.enable_per else "uniform") +
+                                      (", frame-deduplicated" if getattr(memory, "dedup", False) else ""),
                        "optimizer": "adam lr=%g" % ap_.lr, "target_update": ap_.target_model_update,
                        "parallelism": "dp%d" % world, "engine": results[head]["engine"],
                        "precision": head if native else "fp32",

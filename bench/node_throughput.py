@@ -114,7 +114,14 @@ def main():
             infer = json.load(f)
     except (OSError, ValueError):
         pass
+    replay_stats = None
+    try:
+        with open(os.path.join(opt.log_dir, "replay_stats.json")) as f:
+            replay_stats = json.load(f)
+    except (OSError, ValueError):
+        pass
     out = {
+        "replay_stats": replay_stats,
         "bench": "node_throughput", "config": a.config, "agent": opt.agent_type, "env": opt.env_type,
         "model": opt.model_type, "memory": opt.memory_type, "num_actors": opt.num_actors,
         "num_envs_per_actor": opt.num_envs_per_actor,

@@ -643,6 +643,10 @@ def _learner_loop(process_ind, args, global_logs, learner_logs, model_prototype,
             bcast_pub.close()
     if world > 1 and not collective_sync:
         _report_rank_agreement(args, comm, core, rank, step)
+    if rank == 0 and hasattr(global_memory, "stats") and getattr(global_memory, "attached", False):
+        import json
+        with open(os.path.join(args.log_dir, "replay_stats.json"), "w") as f:      # (frame-deduplicated replay)
+            json.dump(global_memory.stats(), f)
     if hasattr(global_memory, "close"):
         global_memory.close()
     if hosted is not None:

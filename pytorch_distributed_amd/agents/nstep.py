@@ -11,6 +11,7 @@
 * with PER the initial priority is |R + gamma^k max_a Q(s_k) - Q(s0, a0)| using
   the actor's own (stale) network.
 """
+import ctypes
 from collections import deque
 
 import numpy as np
@@ -111,8 +112,16 @@ class NativeFeeder(object):
         self.codec, self.ring = c, memory.ring
         self.state_np = c.state_np
         self.timeout_ms = int(timeout_s * 1000)
-        self.h = self.L.pda_nstep_create(int(nstep), float(gamma), 1 if enable_per else 0, c.state_bytes,
-                                         c.state_stride, c.action_shape, c.num_tasks, c.record_bytes)
+        self.dedup = bool(getattr(memory, "dedup", False))
+        if self.dedup:
+            # frame-deduplicated runs (parallel/csrc/frame_runs.h): the assembler sends each frame once
+            rc = memory.run_codec
+            self.h = self.L.pda_nstep_create_dedup(int(nstep), float(gamma), 1 if enable_per else 0, c.state_bytes,
+                                                   rc.window, c.action_shape, c.num_tasks, rc.plane_cap, rc.trans_cap,
+                                                   int(memory.max_age_ms))
+        else:
+            self.h = self.L.pda_nstep_create(int(nstep), float(gamma), 1 if enable_per else 0, c.state_bytes,
+                                             c.state_stride, c.action_shape, c.num_tasks, c.record_bytes)
         if not self.h:
             raise ValueError("n-step assembler: inconsistent record layout")
         self._act = np.zeros(c.action_shape, dtype=np.float32)
@@ -145,6 +154,15 @@ class NativeFeeder(object):
         return self._check(self.L.pda_nstep_flush(self.h, self.ring.base, float(max_qvalue_last) if has else 0.0,
                                                   int(has), self.timeout_ms))
 
+    def ship(self):
+        """Send the open run now (frame-deduplicated records; a no-op otherwise)."""
+        return self._check(self.L.pda_nstep_ship(self.h, self.ring.base, self.timeout_ms))
+
+    def run_stats(self):
+        out = (ctypes.c_uint64 * 3)()
+        self.L.pda_nstep_run_stats(self.h, out)
+        return {"runs": int(out[0]), "planes": int(out[1]), "transitions": int(out[2])}
+
     def __del__(self):
         try:
             if self.h:
@@ -155,6 +173,6 @@ class NativeFeeder(object):
 
 
 def make_feeder(memory, nstep, gamma, enable_per=False, native=True):
-    if native and hasattr(memory, "ring") and hasattr(memory, "codec"):
-        return NativeFeeder(memory, nstep, gamma, enable_per)
+    if (native or getattr(memory, "dedup", False)) and hasattr(memory, "ring") and hasattr(memory, "codec"):
+        return NativeFeeder(memory, nstep, gamma, enable_per)       # (deduplication happens in the native assembler)
     return PythonFeeder(memory, nstep, gamma, enable_per)

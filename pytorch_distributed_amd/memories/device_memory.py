@@ -33,13 +33,16 @@ class DeviceMemory(Memory):
         super().__init__(args)
         self.replay_device = getattr(args, "replay_device", "cpu")
         self.codec = TransitionCodec(self.state_shape, self.state_dtype, self.action_shape, self.reward_shape)
-        self.ring = ShmRing(int(getattr(args, "ingest_ring_slots", 4096)), self.codec.record_bytes)
-        self.ingest_chunk = int(getattr(args, "ingest_chunk", 256))
+        self._make_ring(args)
         self.ingest_device_slabs = int(getattr(args, "ingest_device_slabs", 32))
         self.shared_size = mp.Value("l", 0)     # rank 0's resident transitions, visible to every process
         self.total_fed = mp.Value("l", 0)
         self.attached = False
         self._gen = None
+
+    def _make_ring(self, args):
+        self.ring = ShmRing(int(getattr(args, "ingest_ring_slots", 4096)), self.codec.record_bytes)
+        self.ingest_chunk = int(getattr(args, "ingest_chunk", 256))
 
     # ---- actor face ------------------------------------------------------------
     def feed(self, experience, priority=0.0):
@@ -70,14 +73,20 @@ class DeviceMemory(Memory):
 
     # ---- learner face --------------------------------------------------------------
     def attach(self, device, rank=0, world_size=1):
-        c = self.codec
         self.device = torch.device(device if self.replay_device != "cpu" else "cpu")
         self.rank, self.world_size = rank, world_size
         self.memory_size = max(self.memory_size // world_size, 1)
-        m = self.memory_size
-        dev = self.device
-        self.state0s = torch.zeros((m,) + tuple(self.state_shape), dtype=self.state_dtype, device=dev)
-        self.state1s = torch.zeros((m,) + tuple(self.state_shape), dtype=self.state_dtype, device=dev)
+        self._alloc_storage(self.memory_size, self.device)
+        self._alloc_ingest(self.device, self.ring.payload_bytes)
+        self.tree = DeviceSumMinTree(self.memory_size, self.device) if self.enable_per else None
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(1234 + rank)
+        self.pos, self.full = 0, False
+        self.attached = True
+        return self
+
+    def _alloc_tails(self, m, dev):
+        c = self.codec
         self.tails = torch.zeros(m, c.tail_floats, dtype=torch.float32, device=dev)
         a, k = c.action_shape, c.num_tasks
         self.actions = self.tails[:, :a]
@@ -85,12 +94,19 @@ class DeviceMemory(Memory):
         self.gamma1s = self.tails[:, a + k:a + 2 * k]
         self.terminal1s = self.tails[:, a + 2 * k:a + 3 * k]
         self.init_priorities = self.tails[:, a + 3 * k]
+
+    def _alloc_storage(self, m, dev):
+        self.state0s = torch.zeros((m,) + tuple(self.state_shape), dtype=self.state_dtype, device=dev)
+        self.state1s = torch.zeros((m,) + tuple(self.state_shape), dtype=self.state_dtype, device=dev)
+        self._alloc_tails(m, dev)
+
+    def _alloc_ingest(self, dev, record_bytes):
         # ingestion staging: a small ring of pinned host buffers, each with its device twin and an
         # event, so drain() never waits for the GPU (a buffer is reused only once its copy landed)
         nbuf = 4 if dev.type == "cuda" else 1
         self.staging, self.staging_dev, self.staging_evt = [], [], []
         for _ in range(nbuf):
-            host = torch.zeros(self.ingest_chunk, c.record_bytes, dtype=torch.uint8)
+            host = torch.zeros(self.ingest_chunk, record_bytes, dtype=torch.uint8)
             if dev.type == "cuda":
                 host = host.pin_memory()
                 self.staging_dev.append(torch.zeros_like(host, device=dev))
@@ -111,7 +127,7 @@ class DeviceMemory(Memory):
         if dev.type == "cuda":
             self._copy_stream = torch.cuda.Stream(device=dev)
             nslab = max(2, self.ingest_device_slabs)
-            self._slabs = [torch.zeros(self.ingest_chunk, c.record_bytes, dtype=torch.uint8, device=dev)
+            self._slabs = [torch.zeros(self.ingest_chunk, record_bytes, dtype=torch.uint8, device=dev)
                            for _ in range(nslab)]
             self._slab_free = list(range(nslab))
             self._copy_evt = [torch.cuda.Event() for _ in range(nslab)]
@@ -120,30 +136,28 @@ class DeviceMemory(Memory):
         # learner thread only enqueues DMAs.  Host replay keeps the simple in-line pop.
         self.pump = None
         self._in_flight = []        # [(buffer index, event)] DMAs not yet known complete
-        self._copying = []          # [(slab, records)] chunks whose H2D copy was issued and whose unpack is still due
+        self._copying = []          # [(slab, records, meta)] chunks whose H2D copy was issued, unpack still due
         if dev.type == "cuda" and getattr(self, "use_pump", True):
             import ctypes
             from ..parallel import hostlib
             L = hostlib.lib()
             ptrs = (ctypes.c_void_p * nbuf)(*[t.data_ptr() for t in self.staging])
-            self.pump = L.pda_pump_create(self.ring.base, nbuf, ptrs, self.ingest_chunk, c.record_bytes, 300)
+            self.pump = L.pda_pump_create(self.ring.base, nbuf, ptrs, self.ingest_chunk, record_bytes, 300)
             if not self.pump:
                 raise RuntimeError("ingestion pump could not attach to the ring")
             self._pump_n = ctypes.c_int(0)
             import atexit
             atexit.register(self.close)     # the pump thread must stop before the ring's mapping goes away
         self._pos_base = torch.arange(self.ingest_chunk, device=dev, dtype=torch.int64)
-        self.tree = DeviceSumMinTree(m, dev) if self.enable_per else None
-        self._gen = torch.Generator(device=dev)
-        self._gen.manual_seed(1234 + rank)
-        self.pos, self.full = 0, False
-        self.attached = True
-        return self
+
+    def _chunk_meta(self, host_records, n):
+        """What ingest_records needs to know about a chunk from its HOST copy (read before the DMA is issued)."""
+        return None
 
     def _leaf_priority(self, raw):
         return (raw.abs() + self.priority_eps) ** self.priority_exponent
 
-    def ingest_records(self, records_dev, n):
+    def ingest_records(self, records_dev, n, meta=None):
         """Scatter n packed records (already on the replay device) into the ring."""
         m = self.memory_size
         c = self.codec
@@ -182,12 +196,13 @@ class DeviceMemory(Memory):
             n = self.ring.pop_many(self.staging[i], self.ingest_chunk)
             if n == 0:
                 break
+            meta = self._chunk_meta(self.staging[i], n)
             if cuda:
                 self.staging_dev[i][:n].copy_(self.staging[i][:n], non_blocking=True)
                 if evt is None:
                     evt = self.staging_evt[i] = torch.cuda.Event()
                 evt.record()
-            self.ingest_records(self.staging_dev[i], n)
+            self.ingest_records(self.staging_dev[i], n, meta)
             self._stage_next = (i + 1) % len(self.staging)
             moved += n
             if n < self.ingest_chunk:
@@ -209,10 +224,10 @@ class DeviceMemory(Memory):
         #    updates of stall per chunk when the unpack was ordered behind the copy it had just issued (round 2:
         #    7.4 k updates/s inside the job against 10.4 k alone)
         while self._copying and self._copy_evt[self._copying[0][0]].query():
-            d, n = self._copying.pop(0)
+            d, n, meta = self._copying.pop(0)
             self.chunks_unpacked = getattr(self, "chunks_unpacked", 0) + 1
             learner_stream.wait_event(self._copy_evt[d])    # complete already: an ordering edge, not a stall
-            self.ingest_records(self._slabs[d], n)
+            self.ingest_records(self._slabs[d], n, meta)
             self._unpack_evt[d].record(learner_stream)
             self._slab_busy.append(d)
             moved += n
@@ -225,11 +240,12 @@ class DeviceMemory(Memory):
                 break
             n = self._pump_n.value
             d = self._slab_free.pop(0)
+            meta = self._chunk_meta(self.staging[i], n)
             with torch.cuda.stream(self._copy_stream):
                 self._slabs[d][:n].copy_(self.staging[i][:n], non_blocking=True)
                 self._copy_evt[d].record()
             self._in_flight.append((i, self._copy_evt[d]))
-            self._copying.append((d, n))
+            self._copying.append((d, n, meta))
         return moved
 
     def __del__(self):

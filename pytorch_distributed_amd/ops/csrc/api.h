@@ -42,7 +42,8 @@ PDA_EXPORT void pda_conv1_fwd_u8_x3(const void* const* frames, const void* const
                                     hipStream_t stream);
 PDA_EXPORT int pda_generic_conv1_forced();
 PDA_EXPORT int pda_cnn_fwd_stack_supported(int H, int W, int C);
-PDA_EXPORT void pda_cnn_fwd_stack(const void* const* frames, const void* const* idx, const void* const* w1,
+PDA_EXPORT void pda_cnn_fwd_stack(const void* const* frames, const void* const* idx, const void* const* ref,
+                                  long frame_stride, const void* const* w1,
                                   const void* const* b1, const void* const* w2, const void* const* b2,
                                   const void* const* w3, const void* const* b3, void* const* a1, void* const* a2,
                                   void* const* a3, int ngroups, int batch, int H, int W, int C, float scale,

@@ -64,6 +64,15 @@ __device__ __forceinline__ uint32_t hash_u32(uint64_t x) {
     return (uint32_t)x;
 }
 __device__ __forceinline__ float u01(uint32_t r) { return (r >> 8) * (1.0f / 16777216.0f); }
+// Uniform replay row from a 32-bit random word.  window: int32[4] = {rows to draw from, first row, ring length, -}:
+// row = first + floor(r * rows / 2^32), wrapped at the ring length when that is non-zero (frame-deduplicated replay
+// draws from the newest `rows` transitions of its ring; plain replay has first = 0, ring length = 0).
+__device__ __forceinline__ int window_pick(const int* __restrict__ window, uint32_t r) {
+    const int rows = max(window[0], 1), first = window[1], ring = window[2];
+    int i = first + (int)(((unsigned long long)r * (unsigned long long)rows) >> 32);
+    if (ring > 0 && i >= ring) i -= ring;
+    return i;
+}
 
 #define ACT_NONE 0
 #define ACT_RELU 1

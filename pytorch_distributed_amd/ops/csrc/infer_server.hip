@@ -114,7 +114,7 @@ void enqueue_program(Server& S, int n) {
         if (pda_cnn_fwd_stack_supported(c.H, c.W, c.C)) {
             // the three conv layers in one launch, intermediates in LDS (nature_fwd_stack.hip)
             void* none[1] = {nullptr};
-            pda_cnn_fwd_stack(frames, idx, w0, b0, w1, b1, w2, b2, none, none, o3, 1, n, c.H, c.W, c.C, c.inv_norm, st);
+            pda_cnn_fwd_stack(frames, idx, nullptr, 0, w0, b0, w1, b1, w2, b2, none, none, o3, 1, n, c.H, c.W, c.C, c.inv_norm, st);
         } else {
             pda_conv_fwd_u8(frames, idx, w0, b0, o1, 1, n, c.H, c.W, c.C, 8, 8, 4, 32, c.inv_norm, ACT_RELU, st);
             pda_conv_fwd(x1, w1, b1, o2, 1, n, H1, W1, 32, 4, 4, 2, 64, ACT_RELU, st);

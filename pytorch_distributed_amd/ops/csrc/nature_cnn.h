@@ -52,10 +52,19 @@ __device__ __forceinline__ void patch_issue(PatchRegs& r, const uint8_t* frames,
 // The image number is made opaque so that the index stays a per-lane VGPR load with a counted wait at its
 // use; recognised as wave-uniform it is moved to an SGPR on the spot, behind a vmcnt(0) that also drains the
 // frame loads just issued.
-__device__ __forceinline__ long frame_index(const int* idx, int img, int batch) {
+// ref != null (frame-deduplicated replay, parallel/csrc/frame_runs.h): idx[img] is a transition row and ref[row] the
+// first plane of its frame window in the plane ring; the caller multiplies by the plane stride instead of the stack
+// size.  (One more dependent load, also kept per-lane.)
+__device__ __forceinline__ long frame_index(const int* idx, const int* ref, int img, int batch) {
     int iv = img < batch ? img : 0;
     asm volatile("" : "+v"(iv));
-    return idx ? (long)idx[iv] : (long)iv;
+    if (!idx) return (long)iv;
+    int row = idx[iv];
+    if (ref) {
+        asm volatile("" : "+v"(row));
+        row = ref[row];
+    }
+    return (long)row;
 }
 template <int IT = PATCH_IT>
 __device__ __forceinline__ void patch_issue_at(PatchRegs& r, const uint8_t* frame, long frame_bytes, int tid) {
@@ -108,6 +117,7 @@ __device__ __forceinline__ s16x4 lds_tr4(const bf16_t* p) {
 
 struct FwdStackArgs {
     const uint8_t* frames[GEMM_MAX_GROUPS]; const int* idx[GEMM_MAX_GROUPS];
+    const int* ref[GEMM_MAX_GROUPS]; long frame_stride;    // see frame_index(): bytes between the stacks idx / ref count in
     const bf16_t* w1[GEMM_MAX_GROUPS]; const float* b1[GEMM_MAX_GROUPS];
     const bf16_t* w2[GEMM_MAX_GROUPS]; const float* b2[GEMM_MAX_GROUPS];
     const bf16_t* w3[GEMM_MAX_GROUPS]; const float* b3[GEMM_MAX_GROUPS];

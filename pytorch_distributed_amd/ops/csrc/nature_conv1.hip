@@ -23,6 +23,7 @@ struct Conv1FwdArgs {
     int batch; Conv1Geom g; float scale; int act;
     int parts;      // workgroups per image (small batches: an image's 16-pixel row blocks are split)
     long w_plane, out_plane;    // X3: element offsets to the lo planes of the split weights / outputs
+    const int* ref[GEMM_MAX_GROUPS]; long frame_stride;     // frame_index() in nature_cnn.h
 };
 
 // grid (blocks, groups); each block loops over images blockIdx.x, += gridDim.x.
@@ -59,16 +60,17 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1FwdArgs a) {
     PatchRegs pr;
     const int part = blockIdx.x % a.parts, img0 = blockIdx.x / a.parts, img_step = gridDim.x / a.parts;
     const int rb_beg = part * nrb / a.parts, rb_end = (part + 1) * nrb / a.parts;
-    long f_nxt = frame_index(a.idx[grp], img0 + img_step, a.batch);
+    long f_nxt = frame_index(a.idx[grp], a.ref[grp], img0 + img_step, a.batch);
     if (img0 < a.batch)
-        patch_issue_at(pr, a.frames[grp] + frame_index(a.idx[grp], img0, a.batch) * frame_bytes, frame_bytes, tid);
+        patch_issue_at(pr, a.frames[grp] + frame_index(a.idx[grp], a.ref[grp], img0, a.batch) * a.frame_stride,
+                       frame_bytes, tid);
     for (int img = img0; img < a.batch; img += img_step) {
         __syncthreads();                // everyone is done reading the previous patch
         patch_commit(pr, frame_bytes, patch, tid);
         __syncthreads();
         if (img + img_step < a.batch)           // next image's loads fly under this image's MFMAs
-            patch_issue_at(pr, a.frames[grp] + f_nxt * frame_bytes, frame_bytes, tid);
-        f_nxt = frame_index(a.idx[grp], img + 2 * img_step, a.batch);
+            patch_issue_at(pr, a.frames[grp] + f_nxt * a.frame_stride, frame_bytes, tid);
+        f_nxt = frame_index(a.idx[grp], a.ref[grp], img + 2 * img_step, a.batch);
         bf16_t* out = a.out[grp] + (long)img * P * 32;
         for (int rb = rb_beg + wave; rb < rb_end; rb += 4) {
             int m = rb * 16 + l15;
@@ -107,6 +109,7 @@ struct Conv1WgradArgs {
     int batch; Conv1Geom g; float scale;
     int parts;      // workgroups per image (small batches: the 32-pixel chunks of an image are split)
     long dy_plane;  // X3: element offset from dy's hi plane to its lo plane
+    const int* ref; long frame_stride;      // frame_index() in nature_cnn.h
 };
 
 // LDS: patch [C*H*W] | dyT [PP][32] (T layout, ROWS = 32) | X3: dyT of the lo plane.
@@ -205,9 +208,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
     };
     const int part = blockIdx.x % a.parts, img0 = blockIdx.x / a.parts, img_step = gridDim.x / a.parts;
     const int ch_beg = part * nchunk / a.parts, ch_end = (part + 1) * nchunk / a.parts;
-    long f_nxt = frame_index(a.idx, img0 + img_step, a.batch);
+    long f_nxt = frame_index(a.idx, a.ref, img0 + img_step, a.batch);
     if (img0 < a.batch) {
-        patch_issue_at(pr, a.frames + frame_index(a.idx, img0, a.batch) * frame_bytes, frame_bytes, tid);
+        patch_issue_at(pr, a.frames + frame_index(a.idx, a.ref, img0, a.batch) * a.frame_stride, frame_bytes, tid);
         dy_issue(img0);
     }
     for (int img = img0; img < a.batch; img += img_step) {
@@ -229,10 +232,10 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
         }
         __syncthreads();
         if (img + img_step < a.batch) {         // next image's loads fly under this image's MFMAs
-            patch_issue_at(pr, a.frames + f_nxt * frame_bytes, frame_bytes, tid);
+            patch_issue_at(pr, a.frames + f_nxt * a.frame_stride, frame_bytes, tid);
             dy_issue(img + img_step);
         }
-        f_nxt = frame_index(a.idx, img + 2 * img_step, a.batch);
+        f_nxt = frame_index(a.idx, a.ref, img + 2 * img_step, a.batch);
         // chunks of 32 pixels, fragments of chunk i + 1 in flight under the MFMAs of chunk i (two register
         // sets, the loop advances two chunks per trip; the look-ahead past the end re-reads the last chunk)
         bf16x8 fa0[NA], fb0[4], fa1[NA], fb1[4];
@@ -278,14 +281,18 @@ PDA_EXPORT int pda_conv1_supported(int H, int W, int C, int KH, int KW, int S, i
             (long)C * H * W <= PATCH_IT * 256 * 16 && ((H - 8) / 4 + 1) * ((W - 8) / 4 + 1) <= DY_IT * 64) ? 1 : 0;
 }
 
-PDA_EXPORT void pda_conv1_fwd_u8(const void* const* frames, const void* const* idx, const void* const* w,
-                                 const void* const* bias, void* const* out, int ngroups, int batch, int H, int W,
-                                 int C, float scale, int act, hipStream_t stream) {
+// ref / frame_stride: frame_index() in nature_cnn.h (ref == null or frame_stride == 0: rows of full stacks)
+PDA_EXPORT void pda_conv1_fwd_u8_w(const void* const* frames, const void* const* idx, const void* const* ref,
+                                   long frame_stride, const void* const* w, const void* const* bias, void* const* out,
+                                   int ngroups, int batch, int H, int W, int C, float scale, int act,
+                                   hipStream_t stream) {
     Conv1FwdArgs a;
     for (int i = 0; i < ngroups; ++i) {
         a.frames[i] = (const uint8_t*)frames[i]; a.idx[i] = (const int*)idx[i]; a.w[i] = (const bf16_t*)w[i];
         a.bias[i] = (const float*)bias[i]; a.out[i] = (bf16_t*)out[i];
+        a.ref[i] = ref ? (const int*)ref[i] : nullptr;
     }
+    a.frame_stride = frame_stride > 0 ? frame_stride : (long)C * H * W;
     a.batch = batch; a.g = {C, H, W, (H - 8) / 4 + 1, (W - 8) / 4 + 1}; a.scale = scale; a.act = act;
     a.parts = batch * ngroups <= 128 ? 4 : (batch * ngroups <= 256 ? 2 : 1);
     a.w_plane = 0; a.out_plane = 0;
@@ -293,23 +300,37 @@ PDA_EXPORT void pda_conv1_fwd_u8(const void* const* frames, const void* const* i
     size_t lds = (size_t)C * H * W * 2;
     hipLaunchKernelGGL(conv1_fwd_kernel<4>, dim3(blocks, ngroups), dim3(256), lds, stream, a);
 }
+PDA_EXPORT void pda_conv1_fwd_u8(const void* const* frames, const void* const* idx, const void* const* w,
+                                 const void* const* bias, void* const* out, int ngroups, int batch, int H, int W,
+                                 int C, float scale, int act, hipStream_t stream) {
+    pda_conv1_fwd_u8_w(frames, idx, nullptr, 0, w, bias, out, ngroups, batch, H, W, C, scale, act, stream);
+}
 
 // the same launch for the fp32-precision learner: split weights (lo plane w_plane elements behind hi), split outputs
-PDA_EXPORT void pda_conv1_fwd_u8_x3(const void* const* frames, const void* const* idx, const void* const* w,
-                                    long w_plane, const void* const* bias, void* const* out, long out_plane,
-                                    int ngroups, int batch, int H, int W, int C, float scale, int act,
-                                    hipStream_t stream) {
+PDA_EXPORT void pda_conv1_fwd_u8_x3_w(const void* const* frames, const void* const* idx, const void* const* ref,
+                                      long frame_stride, const void* const* w, long w_plane, const void* const* bias,
+                                      void* const* out, long out_plane, int ngroups, int batch, int H, int W, int C,
+                                      float scale, int act, hipStream_t stream) {
     Conv1FwdArgs a;
     for (int i = 0; i < ngroups; ++i) {
         a.frames[i] = (const uint8_t*)frames[i]; a.idx[i] = (const int*)idx[i]; a.w[i] = (const bf16_t*)w[i];
         a.bias[i] = (const float*)bias[i]; a.out[i] = (bf16_t*)out[i];
+        a.ref[i] = ref ? (const int*)ref[i] : nullptr;
     }
+    a.frame_stride = frame_stride > 0 ? frame_stride : (long)C * H * W;
     a.batch = batch; a.g = {C, H, W, (H - 8) / 4 + 1, (W - 8) / 4 + 1}; a.scale = scale; a.act = act;
     a.parts = batch * ngroups <= 128 ? 4 : (batch * ngroups <= 256 ? 2 : 1);
     a.w_plane = w_plane; a.out_plane = out_plane;
     int blocks = batch * a.parts < 512 ? batch * a.parts : 512;
     size_t lds = (size_t)C * H * W * 2;
     hipLaunchKernelGGL((conv1_fwd_kernel<4, true>), dim3(blocks, ngroups), dim3(256), lds, stream, a);
+}
+PDA_EXPORT void pda_conv1_fwd_u8_x3(const void* const* frames, const void* const* idx, const void* const* w,
+                                    long w_plane, const void* const* bias, void* const* out, long out_plane,
+                                    int ngroups, int batch, int H, int W, int C, float scale, int act,
+                                    hipStream_t stream) {
+    pda_conv1_fwd_u8_x3_w(frames, idx, nullptr, 0, w, w_plane, bias, out, out_plane, ngroups, batch, H, W, C, scale, act,
+                          stream);
 }
 
 // Slices the weight-gradient launch writes for this batch (one per workgroup).
@@ -321,8 +342,9 @@ PDA_EXPORT int pda_conv1_wgrad_slices(int batch) {
 
 PDA_EXPORT void pda_conv1_wgrad_u8(const void* dy, const void* frames, const void* idx, void* gw, void* gb,
                                    int batch, int H, int W, int C, float scale, long slice_stride,
-                                   long bslice_stride, hipStream_t stream) {
+                                   long bslice_stride, const void* ref, long frame_stride, hipStream_t stream) {
     Conv1WgradArgs a;
+    a.ref = (const int*)ref; a.frame_stride = frame_stride > 0 ? frame_stride : (long)C * H * W;
     a.frames = (const uint8_t*)frames; a.idx = (const int*)idx; a.dy = (const bf16_t*)dy;
     a.gw = (float*)gw; a.gb = (float*)gb; a.slice_stride = slice_stride; a.bslice_stride = bslice_stride;
     a.batch = batch; a.g = {C, H, W, (H - 8) / 4 + 1, (W - 8) / 4 + 1}; a.scale = scale;
@@ -342,8 +364,9 @@ PDA_EXPORT void pda_conv1_wgrad_u8(const void* dy, const void* frames, const voi
 // the same launch for the fp32-precision learner: dy as (hi, lo) planes
 PDA_EXPORT void pda_conv1_wgrad_u8_x3(const void* dy, long dy_plane, const void* frames, const void* idx, void* gw,
                                       void* gb, int batch, int H, int W, int C, float scale, long slice_stride,
-                                      long bslice_stride, hipStream_t stream) {
+                                      long bslice_stride, const void* ref, long frame_stride, hipStream_t stream) {
     Conv1WgradArgs a;
+    a.ref = (const int*)ref; a.frame_stride = frame_stride > 0 ? frame_stride : (long)C * H * W;
     a.frames = (const uint8_t*)frames; a.idx = (const int*)idx; a.dy = (const bf16_t*)dy;
     a.gw = (float*)gw; a.gb = (float*)gb; a.slice_stride = slice_stride; a.bslice_stride = bslice_stride;
     a.batch = batch; a.g = {C, H, W, (H - 8) / 4 + 1, (W - 8) / 4 + 1}; a.scale = scale;

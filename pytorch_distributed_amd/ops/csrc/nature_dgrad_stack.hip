@@ -16,6 +16,7 @@ struct DgradStackArgs {
     bf16_t* da2; bf16_t* da1; int batch;
     // optional tail (W1): conv1's weight gradient of the same image, from da1 while it is still in LDS
     const uint8_t* frames; const int* idx; float* gw1; float* gb1; long ws1, bs1; float scale1;
+    const int* ref; long frame_stride;      // frame_index() in nature_cnn.h
     long long* prof;    // optional phase stamps of workgroup 0 (pda_cnn_stack_prof)
 };
 
@@ -60,9 +61,10 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
     long f_nxt = 0;
     if constexpr (W1) {
         const int i0 = img < a.batch ? img : 0;
-        const long f0 = a.idx ? (long)a.idx[i0] : (long)i0;
-        patch_issue_at<7>(pr, a.frames + f0 * frame_bytes, frame_bytes, tid);
-        if constexpr (MULTI) f_nxt = frame_index(a.idx, img + G, a.batch);
+        long f0 = a.idx ? (long)a.idx[i0] : (long)i0;
+        if (a.ref) f0 = (long)a.ref[f0];
+        patch_issue_at<7>(pr, a.frames + f0 * a.frame_stride, frame_bytes, tid);
+        if constexpr (MULTI) f_nxt = frame_index(a.idx, a.ref, img + G, a.batch);
     }
     dgrad_issue(in, a, img < a.batch ? img : 0, tid);       // flies under the weight staging
 
@@ -194,8 +196,8 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_kernel(DgradStackArgs a) 
         __syncthreads();
         if constexpr (MULTI) dgrad_issue(in, a, img + G < a.batch ? img + G : 0, tid);   // unconditional: see cnn_fwd_stack_kernel
         if constexpr (MULTI && W1) {
-            patch_issue_at<7>(pr, a.frames + f_nxt * frame_bytes, frame_bytes, tid);
-            f_nxt = frame_index(a.idx, img + 2 * G, a.batch);
+            patch_issue_at<7>(pr, a.frames + f_nxt * a.frame_stride, frame_bytes, tid);
+            f_nxt = frame_index(a.idx, a.ref, img + 2 * G, a.batch);
         }
 
         STACK_STAMP(a.prof, 0, 3)
@@ -398,7 +400,7 @@ PDA_EXPORT void pda_cnn_dgrad_stack(const void* da3, const void* a2, const void*
                                     void* da2, void* da1, int batch, hipStream_t stream) {
     DgradStackArgs a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3,
                         (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch, nullptr, nullptr, nullptr, nullptr, 0, 0, 1.f,
-                        nullptr};
+                        nullptr, 0, nullptr};
     launch_dgrad_stack(a, stream);
 }
 
@@ -406,9 +408,11 @@ PDA_EXPORT void pda_cnn_dgrad_stack(const void* da3, const void* a2, const void*
 PDA_EXPORT int pda_cnn_dgrad_stack_slices(int batch) { return batch < 256 ? batch : 256; }
 PDA_EXPORT void pda_cnn_dgrad_stack_w1(const void* da3, const void* a2, const void* a1, const void* w3, const void* w2,
                                        void* da2, void* da1, int batch, const void* frames, const void* idx,
-                                       void* gw1, void* gb1, long ws1, long bs1, float scale1, hipStream_t stream) {
+                                       void* gw1, void* gb1, long ws1, long bs1, float scale1, const void* ref,
+                                       long frame_stride, hipStream_t stream) {
     DgradStackArgs a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3,
                         (const bf16_t*)w2, (bf16_t*)da2, (bf16_t*)da1, batch, (const uint8_t*)frames, (const int*)idx,
-                        (float*)gw1, (float*)gb1, ws1, bs1, scale1, nullptr};
+                        (float*)gw1, (float*)gb1, ws1, bs1, scale1, (const int*)ref,
+                        frame_stride > 0 ? frame_stride : 4L * 84 * 84, nullptr};
     launch_dgrad_stack(a, stream);
 }

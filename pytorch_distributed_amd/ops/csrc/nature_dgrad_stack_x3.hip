@@ -24,6 +24,7 @@ struct DgradStackX3Args {
     // optional tail (W1): conv1's weight gradient of the same image, from da1 (hi, lo) while it is still in LDS;
     // slab slice blockIdx.x
     const uint8_t* frames; const int* idx; float* gw1; float* gb1; long ws1, bs1; float scale1;
+    const int* ref; long frame_stride;      // frame_index() in nature_cnn.h
 };
 
 // (hi, lo) planes of 4 gradient values, gated by relu'(act): 8 bytes each
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     constexpr int FH = 84, FW = 84;
     constexpr long frame_bytes = 4L * FH * FW;
     long f0 = 0;
-    if constexpr (W1) f0 = frame_index(a.idx, img, a.batch);      // a per-lane load with a counted wait at its use
+    if constexpr (W1) f0 = frame_index(a.idx, a.ref, img, a.batch);      // a per-lane load with a counted wait at its use
 
     STACK_STAMP(a.prof, 0, 0)
     // ---- conv3's weight fragments (both planes) and this image's inputs (a1 / a2: hi planes only) go out together;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
 #pragma unroll
     for (int t = 0; t < 8; ++t) { pin_agpr(wf2h[t][0]); pin_agpr(wf2h[t][1]); pin_agpr(wf2l[t][0]); pin_agpr(wf2l[t][1]); }
     PatchRegs pr;
-    if constexpr (W1) patch_issue_at<7>(pr, a.frames + f0 * frame_bytes, frame_bytes, tid);     // flies under conv2^T
+    if constexpr (W1) patch_issue_at<7>(pr, a.frames + f0 * a.frame_stride, frame_bytes, tid);     // flies under conv2^T
     STACK_STAMP(a.prof, 0, 5)
     // ---- conv2^T for this wave's parity class: input pixel (2 iy2 + py, 2 ix2 + px), taps (py + 2a, px + 2b)
     {
@@ -388,11 +389,12 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
 PDA_EXPORT void pda_cnn_dgrad_stack_x3(const void* da3, long da3_plane, const void* a2, const void* a1,
                                        const void* w3t, const void* w2t, long w_plane, void* da2, long da2_plane,
                                        void* da1, long da1_plane, int batch, const void* frames, const void* idx,
-                                       void* gw1, void* gb1, long ws1, long bs1, float scale1, hipStream_t stream) {
+                                       void* gw1, void* gb1, long ws1, long bs1, float scale1, const void* ref,
+                                       long frame_stride, hipStream_t stream) {
     DgradStackX3Args a = {(const bf16_t*)da3, (const bf16_t*)a2, (const bf16_t*)a1, (const bf16_t*)w3t,
                           (const bf16_t*)w2t, (bf16_t*)da2, (bf16_t*)da1, batch, da3_plane, w_plane, da2_plane, da1_plane,
                           g_pda_stack_prof, (const uint8_t*)frames, (const int*)idx, (float*)gw1, (float*)gb1, ws1, bs1,
-                          scale1};
+                          scale1, (const int*)ref, frame_stride > 0 ? frame_stride : 4L * 84 * 84};
     static_assert(DX_LDS_ELEMS * 2 <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {

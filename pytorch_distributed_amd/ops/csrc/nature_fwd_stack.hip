@@ -48,10 +48,11 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
     }
     PatchRegs pr;                           // frame loads next: the other weights arrive behind them
     const int G = gridDim.x;
-    long f_nxt = MULTI ? frame_index(a.idx[grp], blockIdx.x + G, a.batch) : 0;
+    long f_nxt = MULTI ? frame_index(a.idx[grp], a.ref[grp], blockIdx.x + G, a.batch) : 0;
     if ((int)blockIdx.x < a.batch) {       // first image: the index is needed at once, as a scalar
-        const long f0 = a.idx[grp] ? (long)a.idx[grp][blockIdx.x] : (long)blockIdx.x;
-        patch_issue_at<7>(pr, a.frames[grp] + f0 * frame_bytes, frame_bytes, tid);
+        long f0 = a.idx[grp] ? (long)a.idx[grp][blockIdx.x] : (long)blockIdx.x;
+        if (a.ref[grp]) f0 = (long)a.ref[grp][f0];
+        patch_issue_at<7>(pr, a.frames[grp] + f0 * a.frame_stride, frame_bytes, tid);
     }
     // weight fragments (lane: channel n = l15 + 16 nb, 8 consecutive k).  conv1's k-steps are regrouped as
     // (ky = ks, c = g4, kx 0..7) -- any order works as long as both operands agree -- see conv1 below.
@@ -145,8 +146,8 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_kernel(FwdStackArgs a) {
         // unconditional (past the end: frame_index clamps to image 0): a conditional issue leaves the
         // compiler merging old and new registers with copies that wait for the loads on the spot
         if constexpr (MULTI) {
-            patch_issue_at<7>(pr, a.frames[grp] + f_nxt * frame_bytes, frame_bytes, tid);
-            f_nxt = frame_index(a.idx[grp], img + 2 * G, a.batch);     // consumed one image from now
+            patch_issue_at<7>(pr, a.frames[grp] + f_nxt * a.frame_stride, frame_bytes, tid);
+            f_nxt = frame_index(a.idx[grp], a.ref[grp], img + 2 * G, a.batch);     // consumed one image from now
         }
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) { pin_agpr(wf1[ks][0]); pin_agpr(wf1[ks][1]); }
@@ -337,7 +338,9 @@ PDA_EXPORT void pda_cnn_stack_prof(void* buf) { g_pda_stack_prof = (long long*)b
 // Layer shapes are the Nature ones: 8x8 s4 x32, 4x4 s2 x64, 3x3 s1 x64 on C = 4 frame stacks.
 PDA_EXPORT int pda_cnn_fwd_stack_supported(int H, int W, int C) { return (H == 84 && W == 84 && C == 4) ? 1 : 0; }
 
-PDA_EXPORT void pda_cnn_fwd_stack(const void* const* frames, const void* const* idx, const void* const* w1,
+// ref / frame_stride: frame_index() in nature_cnn.h (ref == null or frame_stride == 0: rows of full stacks).
+PDA_EXPORT void pda_cnn_fwd_stack(const void* const* frames, const void* const* idx, const void* const* ref,
+                                  long frame_stride, const void* const* w1,
                                   const void* const* b1, const void* const* w2, const void* const* b2,
                                   const void* const* w3, const void* const* b3, void* const* a1, void* const* a2,
                                   void* const* a3, int ngroups, int batch, int H, int W, int C, float scale,
@@ -345,12 +348,14 @@ PDA_EXPORT void pda_cnn_fwd_stack(const void* const* frames, const void* const* 
     FwdStackArgs a;
     for (int i = 0; i < ngroups; ++i) {
         a.frames[i] = (const uint8_t*)frames[i]; a.idx[i] = (const int*)idx[i];
+        a.ref[i] = ref ? (const int*)ref[i] : nullptr;
         a.w1[i] = (const bf16_t*)w1[i]; a.b1[i] = (const float*)b1[i];
         a.w2[i] = (const bf16_t*)w2[i]; a.b2[i] = (const float*)b2[i];
         a.w3[i] = (const bf16_t*)w3[i]; a.b3[i] = (const float*)b3[i];
         a.a1[i] = (bf16_t*)a1[i]; a.a2[i] = (bf16_t*)a2[i]; a.a3[i] = (bf16_t*)a3[i];
     }
     a.batch = batch; a.scale = scale; a.prof = g_pda_stack_prof;
+    a.frame_stride = frame_stride > 0 ? frame_stride : (long)C * H * W;
     size_t lds = ((size_t)4 * FWD_PLANE + (size_t)20 * F1_RP) * 2;
     static bool attr_set = false;
     if (!attr_set) {

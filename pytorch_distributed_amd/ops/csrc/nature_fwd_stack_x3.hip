@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
     }
     PatchRegs pr;
     {
-        const long f0 = a.idx[grp] ? (long)a.idx[grp][img] : (long)img;
-        patch_issue_at<7>(pr, a.frames[grp] + f0 * frame_bytes, frame_bytes, tid);
+        long f0 = a.idx[grp] ? (long)a.idx[grp][img] : (long)img;
+        if (a.ref[grp]) f0 = (long)a.ref[grp][f0];
+        patch_issue_at<7>(pr, a.frames[grp] + f0 * a.frame_stride, frame_bytes, tid);
     }
     STACK_STAMP(a.prof, 0, 10)
     // conv2's weights are fetched under conv1's MFMAs, conv3's under conv2's: issued here they would share the L2 -> L1
@@ -326,7 +327,8 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
 
 // the same at fp32 precision: split weights (lo plane w_plane elements behind hi; one shadow buffer per network, so
 // one offset for the three layers) and split activations.  One workgroup per image and network.
-PDA_EXPORT void pda_cnn_fwd_stack_x3(const void* const* frames, const void* const* idx, const void* const* w1,
+PDA_EXPORT void pda_cnn_fwd_stack_x3(const void* const* frames, const void* const* idx, const void* const* ref,
+                                     long frame_stride, const void* const* w1,
                                      const void* const* b1, const void* const* w2, const void* const* b2,
                                      const void* const* w3, const void* const* b3, long w_plane, void* const* a1,
                                      long a1_plane, void* const* a2, long a2_plane, void* const* a3, long a3_plane,
@@ -334,12 +336,14 @@ PDA_EXPORT void pda_cnn_fwd_stack_x3(const void* const* frames, const void* cons
     FwdStackArgs a;
     for (int i = 0; i < ngroups; ++i) {
         a.frames[i] = (const uint8_t*)frames[i]; a.idx[i] = (const int*)idx[i];
+        a.ref[i] = ref ? (const int*)ref[i] : nullptr;
         a.w1[i] = (const bf16_t*)w1[i]; a.b1[i] = (const float*)b1[i];
         a.w2[i] = (const bf16_t*)w2[i]; a.b2[i] = (const float*)b2[i];
         a.w3[i] = (const bf16_t*)w3[i]; a.b3[i] = (const float*)b3[i];
         a.a1[i] = (bf16_t*)a1[i]; a.a2[i] = (bf16_t*)a2[i]; a.a3[i] = (bf16_t*)a3[i];
     }
     a.batch = batch; a.scale = scale; a.prof = g_pda_stack_prof;
+    a.frame_stride = frame_stride > 0 ? frame_stride : (long)C * H * W;
     a.w_plane = w_plane; a.a1_plane = a1_plane; a.a2_plane = a2_plane; a.a3_plane = a3_plane;
     size_t lds = ((size_t)4 * FWD_PLANE + 2 * (size_t)X_A1LO) * 2;
     static bool attr_set = false;

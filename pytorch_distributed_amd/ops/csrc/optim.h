@@ -133,9 +133,8 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
         int i = (bid - nchunks) * 256 + threadIdx.x;
         if (i < x.next_B) {
             unsigned long long ctr = *x.counter;
-            int n = max(*x.size, 1);
             uint32_t r = hash_u32(x.seed ^ (ctr * 0x9e3779b97f4a7c15ULL + (unsigned long long)i + 1));
-            x.next_idx[i] = (int)(((unsigned long long)r * (unsigned long long)n) >> 32);
+            x.next_idx[i] = window_pick(x.size, r);
             if (x.next_w) x.next_w[i] = 1.f;
         }
         return;

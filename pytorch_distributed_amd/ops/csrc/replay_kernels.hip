@@ -1,6 +1,7 @@
 // Prioritized-replay segment tree (radix 64 = one child per wavefront lane) and
 // HBM replay data movement.
 #include "common.h"
+#include "../../parallel/csrc/frame_runs.h"
 
 #define RADIX 64
 
@@ -112,15 +113,15 @@ PDA_EXPORT void pda_segtree_sample_rng(const void* sum, const void* mn, const in
                        (int*)out_idx, (float*)out_w, seed, (const unsigned long long*)counter);
 }
 
-// uniform index draw on device (counter-based, graph-replayable: the counter lives in memory)
+// uniform index draw on device (counter-based, graph-replayable: the counter lives in memory).
+// size: int32[4] = {rows to draw from, first row, ring length (0: no wrap), -} (common.h window_pick)
 __global__ void uniform_idx_kernel(int* out_idx, float* out_w, int B, const int* size, unsigned long long seed,
                                    unsigned long long* counter) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long ctr = *counter;
     if (i < B) {
-        int n = max(*size, 1);
         uint32_t r = hash_u32(seed ^ (ctr * 0x9e3779b97f4a7c15ULL + (unsigned long long)i + 1));
-        out_idx[i] = (int)(((unsigned long long)r * (unsigned long long)n) >> 32);
+        out_idx[i] = window_pick(size, r);
         if (out_w) out_w[i] = 1.f;
     }
 }
@@ -192,4 +193,66 @@ PDA_EXPORT void pda_replay_gather(const void* src, const void* idx, int B, int r
                                   hipStream_t stream) {
     hipLaunchKernelGGL(replay_gather_kernel, dim3(B), dim3(256), 0, stream, (const uint8_t*)src, (const int*)idx,
                        row_bytes, (uint8_t*)out);
+}
+
+// ---- frame-deduplicated replay: unpack run records (parallel/csrc/frame_runs.h) ----------------------------
+// Workgroup (j, r): plane j and transition j of run r.  The planes of a run land contiguously at plane_base[r] of the
+// plane ring; a transition's two window offsets become plane indices of that ring.  Workgroup (0, 0) also publishes the
+// sampling window {rows, first row, ring length} that is valid once this chunk is in (the host computed it; written
+// here so that it changes in stream order with the data, without launches of its own).
+#define PDA_MAX_RUNS 16
+struct RunPlacement { int plane_base[PDA_MAX_RUNS]; int trans_pos[PDA_MAX_RUNS]; };
+
+__global__ __launch_bounds__(256) void replay_unpack_runs_kernel(const uint8_t* __restrict__ rec, long rec_stride,
+                                                                 RunPlacement pl, int trans_ring,
+                                                                 uint8_t* __restrict__ planes, int plane_stride,
+                                                                 int planes_off, int trans_stride, int tail_floats,
+                                                                 float* __restrict__ tails, int tail_ld,
+                                                                 int* __restrict__ ref0, int* __restrict__ refN,
+                                                                 int* __restrict__ window, int w_rows, int w_first,
+                                                                 int w_ring) {
+    const int j = blockIdx.x, r = blockIdx.y;
+    const uint8_t* src = rec + (long)r * rec_stride;
+    const PdaRunHeader* h = reinterpret_cast<const PdaRunHeader*>(src);
+    const int np = h->num_planes, nt = h->num_transitions;
+    const int base = pl.plane_base[r];
+    if (j < np) {
+        const uint4* a = reinterpret_cast<const uint4*>(src + planes_off + (long)j * plane_stride);
+        uint4* d = reinterpret_cast<uint4*>(planes + (long)(base + j) * plane_stride);
+        for (int i = threadIdx.x; i < plane_stride / 16; i += blockDim.x) d[i] = a[i];
+    }
+    if (j < nt) {
+        const uint8_t* e = src + sizeof(PdaRunHeader) + (long)j * trans_stride;
+        int slot = pl.trans_pos[r] + j;
+        if (slot >= trans_ring) slot -= trans_ring;
+        const float* tl = reinterpret_cast<const float*>(e);
+        if ((int)threadIdx.x < tail_floats) tails[(long)slot * tail_ld + threadIdx.x] = tl[threadIdx.x];
+        if (threadIdx.x == 64) {
+            const int* offs = reinterpret_cast<const int*>(e + 4 * tail_floats);
+            ref0[slot] = base + offs[0];
+            refN[slot] = base + offs[1];
+        }
+    }
+    if (j == 0 && r == 0 && threadIdx.x == 128 && window) {
+        window[0] = w_rows; window[1] = w_first; window[2] = w_ring;
+    }
+}
+PDA_EXPORT int pda_replay_unpack_runs(const void* rec, long rec_stride, int n_runs, const int* plane_base,
+                                      const int* trans_pos, int trans_ring, void* planes, int plane_stride,
+                                      int plane_cap, int trans_cap, int tail_floats, void* tails, int tail_ld,
+                                      void* ref0, void* refN, void* window, int w_rows, int w_first, int w_ring,
+                                      hipStream_t stream) {
+    if (n_runs < 1 || n_runs > PDA_MAX_RUNS || plane_stride % 16 != 0 || tail_floats > 64) return -1;
+    RunPlacement pl;
+    for (int i = 0; i < PDA_MAX_RUNS; ++i) {
+        pl.plane_base[i] = i < n_runs ? plane_base[i] : 0;
+        pl.trans_pos[i] = i < n_runs ? trans_pos[i] : 0;
+    }
+    const int gx = plane_cap > trans_cap ? plane_cap : trans_cap;
+    hipLaunchKernelGGL(replay_unpack_runs_kernel, dim3(gx, n_runs), dim3(256), 0, stream, (const uint8_t*)rec,
+                       rec_stride, pl, trans_ring, (uint8_t*)planes, plane_stride,
+                       (int)pda_run_planes_offset((uint32_t)tail_floats, (uint32_t)trans_cap),
+                       (int)pda_run_trans_stride((uint32_t)tail_floats), tail_floats, (float*)tails, tail_ld, (int*)ref0,
+                       (int*)refN, (int*)window, w_rows, w_first, w_ring);
+    return 0;
 }

@@ -94,7 +94,7 @@ class DqnCnnEngine(object):
         self.q = torch.zeros(self.B, g.A, dtype=torch.float32, device=dev)
         self.loss_acc = torch.zeros(self.B, dtype=torch.float32, device=dev)     # per-sample sums (no atomics)
         self.loss_steps = 0
-        self.size_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.size_dev = torch.zeros(4, dtype=torch.int32, device=dev)    # {rows, first row, ring length, -}: csrc/common.h window_pick
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         self.seed = int(seed) & 0xFFFFFFFFFFFF
         self.tail_offsets = tuple(int(o) for o in tail_offsets)
@@ -165,9 +165,20 @@ class DqnCnnEngine(object):
         self.slabinfo = info.to(dev)
 
     # ---- data sources --------------------------------------------------------------------------
-    def bind_replay(self, state0s, state1s, tails, tree=None):
-        """HBM replay: uint8 [M,C,H,W] x2 and fp32 tails [M][tail_ld] on this device."""
-        assert state0s.dtype == torch.uint8 and state0s.is_cuda and tails.dtype == torch.float32
+    def bind_replay(self, state0s, state1s, tails, tree=None, window=None):
+        """HBM replay: uint8 [M,C,H,W] x2 and fp32 tails [M][tail_ld] on this device -- or, frame-deduplicated
+        (memories/dedup_memory.py), two nn.FrameWindows over one plane store plus the memory's sampling window
+        (int32[4] on the device, kept by its unpack kernel), which then replaces this engine's own size word."""
+        if isinstance(state0s, nn.FrameWindows):
+            g = self.geom
+            if not (nn.cnn_fwd_stack_supported(g.H, g.W, g.C) or nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32)):
+                raise ValueError("frame-deduplicated replay needs the Nature-CNN kernels (4 x 84 x 84 frame stacks)")
+            assert state0s.store.is_cuda and state0s.window == g.C and window is not None and window.numel() >= 3
+            assert state0s.stride == g.H * g.W, "a plane of the store is one H x W frame"
+            self.size_dev = window
+        else:
+            assert state0s.dtype == torch.uint8 and state0s.is_cuda
+        assert tails.dtype == torch.float32
         self.replay = (state0s, state1s, tails, tree)
         return self
 
@@ -353,7 +364,7 @@ class DqnCnnEngine(object):
         self._target_copy(1.0)
 
     def set_size(self, n):
-        self.size_dev.fill_(int(n))
+        self.size_dev[:1].fill_(int(n))
 
     def mean_loss(self, lagged=False):
         """Mean loss since the last call (one host sync).  lagged: no synchronisation -- the value returned is the
@@ -390,7 +401,11 @@ class DqnNativeCore(object):
                                    seed=args.seed * 7919 + 104729 * rank + 13, tail_offsets=(0, a, a + k, a + 2 * k),
                                    precision=getattr(args, "precision", "bf16"), knobs=resolve_knobs(args))
         self.on_device = hasattr(memory, "tails") and getattr(memory, "attached", False) and memory.tails.is_cuda
-        if self.on_device:
+        self.dedup = bool(getattr(memory, "dedup", False))
+        if self.on_device and self.dedup:
+            s0, s_n = memory.frame_windows()
+            self.engine.bind_replay(s0, s_n, memory.tails, memory.tree, window=memory.window_dev)
+        elif self.on_device:
             self.engine.bind_replay(memory.state0s, memory.state1s, memory.tails, memory.tree)
         else:
             self.engine.make_staging(a + 3 * k + 1)
@@ -404,7 +419,7 @@ class DqnNativeCore(object):
         e = self.engine
         if self.on_device:
             n = self.memory.size
-            if n != self._last_size:
+            if n != self._last_size and not self.dedup:     # (deduplicated replay publishes its own sampling window)
                 e.set_size(n)
                 self._last_size = n
             self.program.step()

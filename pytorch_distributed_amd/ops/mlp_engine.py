@@ -217,7 +217,7 @@ class _EngineBase(object):
         self.per_sample_loss = per_sample_loss
         self.loss_acc = torch.zeros(self.B if per_sample_loss else n_losses, dtype=torch.float32, device=dev)
         self.loss_steps = 0
-        self.size_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.size_dev = torch.zeros(4, dtype=torch.int32, device=dev)    # {rows, first row, ring length, -}: csrc/common.h window_pick
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         self.seed = int(seed) & 0xFFFFFFFFFFFF
         self.tail_offsets = tuple(int(o) for o in tail_offsets)
@@ -257,7 +257,7 @@ class _EngineBase(object):
                               _stream())
 
     def set_size(self, n):
-        self.size_dev.fill_(int(n))
+        self.size_dev[:1].fill_(int(n))
 
     def _finish_update(self, staged):
         if not staged and self.per is not None and self.replay[3] is not None:

@@ -37,6 +37,38 @@ def _stream():
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 
+class FrameWindows(object):
+    """Frame stacks read as windows of a plane store (frame-deduplicated replay, memories/dedup_memory.py):
+    image b of a batch is the `window` consecutive planes that start at plane ref[idx[b]] of `store`
+    (uint8 [planes, plane_bytes]).  Accepted wherever the Nature-CNN kernels take `frames` (csrc/nature_cnn.h
+    frame_index); the generic implicit-GEMM conv1 kernels do not read windows."""
+
+    def __init__(self, store, ref, window):
+        assert store.dtype == torch.uint8 and store.dim() == 2 and ref.dtype == torch.int32
+        assert store.stride(0) % 16 == 0
+        self.store, self.ref, self.window = store, ref, int(window)
+        self.stride = int(store.stride(0))
+
+    def data_ptr(self):
+        return self.store.data_ptr()
+
+
+def _windows(frames):
+    """-> (ref tensors or None per entry, plane stride or 0) for a list of frame sources."""
+    refs = [f.ref if isinstance(f, FrameWindows) else None for f in frames]
+    strides = {f.stride for f in frames if isinstance(f, FrameWindows)}
+    if not strides:
+        return refs, 0
+    if len(strides) != 1 or any(r is None for r in refs):
+        raise ValueError("frame sources of one launch must all be windows of stores with one plane stride, or none")
+    return refs, strides.pop()
+
+
+def _no_windows(frames, what):
+    if any(isinstance(f, FrameWindows) for f in (frames if isinstance(frames, (list, tuple)) else [frames])):
+        raise ValueError("%s reads full frame stacks only (frame-deduplicated replay needs the Nature-CNN kernels)" % what)
+
+
 _configured = False
 
 
@@ -56,15 +88,15 @@ def _L():
         L.pda_col2im.argtypes = [_vp] * 3 + [c_int] * 8 + [_vp]
         L.pda_conv1_supported.argtypes = [c_int] * 7
         L.pda_conv1_supported.restype = c_int
-        L.pda_conv1_fwd_u8.argtypes = [_vp] * 5 + [c_int] * 5 + [c_float, c_int, _vp]
-        L.pda_conv1_fwd_u8.restype = None
+        L.pda_conv1_fwd_u8_w.argtypes = [_vp] * 3 + [c_long] + [_vp] * 3 + [c_int] * 5 + [c_float, c_int, _vp]
+        L.pda_conv1_fwd_u8_w.restype = None
         L.pda_conv1_wgrad_slices.argtypes = [c_int]
         L.pda_conv1_wgrad_slices.restype = c_int
-        L.pda_conv1_wgrad_u8.argtypes = [_vp] * 5 + [c_int] * 4 + [c_float, c_long, c_long, _vp]
+        L.pda_conv1_wgrad_u8.argtypes = [_vp] * 5 + [c_int] * 4 + [c_float, c_long, c_long, _vp, c_long, _vp]
         L.pda_conv1_wgrad_u8.restype = None
         L.pda_cnn_fwd_stack_supported.argtypes = [c_int] * 3
         L.pda_cnn_fwd_stack_supported.restype = c_int
-        L.pda_cnn_fwd_stack.argtypes = [_vp] * 11 + [c_int] * 5 + [c_float, _vp]
+        L.pda_cnn_fwd_stack.argtypes = [_vp] * 3 + [c_long] + [_vp] * 9 + [c_int] * 5 + [c_float, _vp]
         L.pda_cnn_fwd_stack.restype = None
         L.pda_cnn_dgrad_stack_supported.argtypes = [c_int] * 3
         L.pda_cnn_dgrad_stack_supported.restype = c_int
@@ -114,8 +146,9 @@ def cnn_fwd_stack(frames, idx, w1, b1, w2, b2, w3, b3, a1, a2, a3, batch, H, W, 
     """Nature-CNN conv stack forward, one workgroup per image, every intermediate in LDS.  Lists with one
     entry per problem group (<= 4); a1 / a2 entries may be None (activations not needed for a backward)."""
     n = len(frames)
-    _L().pda_cnn_fwd_stack(_arr(frames), _arr(idx), _arr(w1), _arr(b1), _arr(w2), _arr(b2), _arr(w3), _arr(b3),
-                           _arr(a1), _arr(a2), _arr(a3), n, batch, H, W, C, float(scale), _stream())
+    refs, stride = _windows(frames)
+    _L().pda_cnn_fwd_stack(_arr(frames), _arr(idx), _arr(refs), stride, _arr(w1), _arr(b1), _arr(w2), _arr(b2),
+                           _arr(w3), _arr(b3), _arr(a1), _arr(a2), _arr(a3), n, batch, H, W, C, float(scale), _stream())
 
 
 def cnn_dgrad_stack_supported(H, W, C):
@@ -141,12 +174,14 @@ def cnn_dgrad_stack(da3, a2, a1, w3, w2, da2, da1, batch, w1=None):
         return
     if not getattr(L, "_dgw1_ready", False):
         L.pda_cnn_dgrad_stack_w1.argtypes = ([_vp] * 7 + [ctypes.c_int] + [_vp] * 4 + [ctypes.c_long, ctypes.c_long,
-                                             ctypes.c_float, _vp])
+                                             ctypes.c_float, _vp, ctypes.c_long, _vp])
         L.pda_cnn_dgrad_stack_w1.restype = None
         L._dgw1_ready = True
     frames, idx, gw, gb, scale = w1
+    (ref,), stride = _windows([frames])
     L.pda_cnn_dgrad_stack_w1(_ptr(da3), _ptr(a2), _ptr(a1), _ptr(w3), _ptr(w2), _ptr(da2), _ptr(da1), int(batch),
-                             _ptr(frames), _ptr(idx), _ptr(gw), _ptr(gb), 32 * 256, 32, float(scale), _stream())
+                             _ptr(frames), _ptr(idx), _ptr(gw), _ptr(gb), 32 * 256, 32, float(scale), _ptr(ref), stride,
+                             _stream())
 
 
 def cnn_wgrad_stack_slices(batch):
@@ -176,9 +211,11 @@ def conv_fwd_u8(frames, idx, w, bias, out, batch, H, W, C, KH, KW, S, O, scale, 
     """Lists (one entry per problem group, <= 3).  frames: uint8 [*, C, H, W]; idx: int32 [batch] or None."""
     assert KW == 8 and len(frames) <= 3
     if conv1_specialised(H, W, C, KH, KW, S, O):
-        _L().pda_conv1_fwd_u8(_arr(frames), _arr(idx), _arr(w), _arr(bias), _arr(out), len(frames), batch,
-                              H, W, C, float(scale), act, _stream())
+        refs, stride = _windows(frames)
+        _L().pda_conv1_fwd_u8_w(_arr(frames), _arr(idx), _arr(refs), stride, _arr(w), _arr(bias), _arr(out),
+                                len(frames), batch, H, W, C, float(scale), act, _stream())
         return
+    _no_windows(frames, "the generic conv1 forward")
     _L().pda_conv_fwd_u8(_arr(frames), _arr(idx), _arr(w), _arr(bias), _arr(out), len(frames), batch,
                          H, W, C, KH, KW, S, O, float(scale), act, _stream())
 
@@ -324,9 +361,11 @@ def conv_wgrad_u8(dy, frames, idx, gw, gb, batch, H, W, C, KH, KW, S, O, scale, 
     if conv1_specialised(H, W, C, KH, KW, S, O):
         # one slice per workgroup (conv1_wgrad_slices(batch) of them); ksplit is not used
         assert conv1_wgrad_slices(batch) == 1 or slice_stride >= O * C * KH * KW
+        (ref,), stride = _windows([frames])
         _L().pda_conv1_wgrad_u8(_ptr(dy), _ptr(frames), _ptr(idx), _ptr(gw), _ptr(gb), batch, H, W, C,
-                                float(scale), slice_stride, bslice_stride, _stream())
+                                float(scale), slice_stride, bslice_stride, _ptr(ref), stride, _stream())
         return
+    _no_windows(frames, "the generic conv1 weight gradient")
     _L().pda_conv_wgrad_u8(_ptr(dy), _ptr(frames), _ptr(idx), _ptr(gw), _ptr(gb), batch, H, W, C, KH, KW, S, O,
                            float(scale), slice_stride, bslice_stride, ksplit, _stream())
 
@@ -446,11 +485,14 @@ def _X():
         L.pda_x3_conv_wgrad.argtypes = [_vp] * 6 + [c_int, c_int] + [_vp] * 6 + [c_int, _vp, _vp, c_int, _vp]
         L.pda_x3_conv_wgrad_u8.argtypes = ([_vp, c_long, _vp, _vp, _vp, _vp] + [c_int] * 8 +
                                            [c_float, c_long, c_long, c_int, _vp])
-        L.pda_cnn_fwd_stack_x3.argtypes = ([_vp] * 8 + [c_long, _vp, c_long, _vp, c_long, _vp, c_long] + [c_int] * 5 +
-                                           [c_float, _vp])
+        L.pda_cnn_fwd_stack_x3.argtypes = ([_vp] * 3 + [c_long] + [_vp] * 6 +
+                                           [c_long, _vp, c_long, _vp, c_long, _vp, c_long] + [c_int] * 5 + [c_float, _vp])
+        L.pda_conv1_fwd_u8_x3_w.argtypes = ([_vp] * 3 + [c_long, _vp, c_long, _vp, _vp, c_long] + [c_int] * 5 +
+                                            [c_float, c_int, _vp])
+        L.pda_conv1_fwd_u8_x3_w.restype = None
         L.pda_cnn_fwd_stack_x3.restype = None
         L.pda_cnn_dgrad_stack_x3.argtypes = ([_vp, c_long, _vp, _vp, _vp, _vp, c_long, _vp, c_long, _vp, c_long, c_int] +
-                                             [_vp] * 4 + [c_long, c_long, c_float, _vp])
+                                             [_vp] * 4 + [c_long, c_long, c_float, _vp, c_long, _vp])
         L.pda_cnn_dgrad_stack_x3.restype = None
         for name in ("pda_x3_conv_fwd_u8", "pda_x3_conv_fwd", "pda_x3_linear_fwd", "pda_x3_linear_dgrad",
                      "pda_x3_conv_dgrad", "pda_x3_linear_wgrad2", "pda_x3_fc_backward_duo", "pda_x3_conv_wgrad",
@@ -477,6 +519,13 @@ def _ints(vals):
 def x3_conv_fwd_u8(frames, idx, w, bias, out, batch, H, W, C, KH, KW, S, O, scale, act=ACT_RELU):
     """conv_fwd_u8 with split weights (Planes) and split outputs; frames are exact."""
     assert KW == 8 and len(frames) <= GEMM_MAX_GROUPS and (C * KH * KW) % 8 == 0
+    refs, stride = _windows(frames)
+    if stride:
+        if not conv1_specialised(H, W, C, KH, KW, S, O):
+            _no_windows(frames, "the generic conv1 forward")
+        _X().pda_conv1_fwd_u8_x3_w(_arr(frames), _arr(idx), _arr(refs), stride, _arr(w), _same_plane(w), _arr(bias),
+                                   _arr(out), _same_plane(out), len(frames), batch, H, W, C, float(scale), act, _stream())
+        return
     _X().pda_x3_conv_fwd_u8(_arr(frames), _arr(idx), _arr(w), _same_plane(w), _arr(bias), _arr(out), _same_plane(out),
                             len(frames), batch, H, W, C, KH, KW, S, O, float(scale), act, _stream())
 
@@ -493,7 +542,9 @@ def x3_cnn_fwd_stack(frames, idx, w1, b1, w2, b2, w3, b3, a1, a2, a3, batch, H, 
     assert n <= GEMM_MAX_GROUPS and H == 84 and W == 84 and C == 4
     wp = _same_plane(list(w1) + list(w2) + list(w3))
     kept1, kept2 = [t for t in a1 if t is not None], [t for t in a2 if t is not None]
-    _X().pda_cnn_fwd_stack_x3(_arr(frames), _arr(idx), _arr(w1), _arr(b1), _arr(w2), _arr(b2), _arr(w3), _arr(b3), wp,
+    refs, stride = _windows(frames)
+    _X().pda_cnn_fwd_stack_x3(_arr(frames), _arr(idx), _arr(refs), stride, _arr(w1), _arr(b1), _arr(w2), _arr(b2),
+                              _arr(w3), _arr(b3), wp,
                               _arr(a1), _same_plane(kept1) if kept1 else 0, _arr(a2),
                               _same_plane(kept2) if kept2 else 0, _arr(a3), _same_plane(a3), n, batch, H, W, C,
                               float(scale), _stream())
@@ -511,9 +562,10 @@ def x3_cnn_dgrad_stack(da3, a2_hi, a1_hi, w3t, w2t, da2, da1, batch, w1=None):
     also leaves conv1's weight / bias gradient, one slab slice per workgroup (two workgroups share an image)."""
     assert _plane(w3t) == _plane(w2t)
     frames, idx, gw, gb, scale = w1 if w1 is not None else (None, None, None, None, 1.0)
+    (ref,), stride = _windows([frames])
     _X().pda_cnn_dgrad_stack_x3(_ptr(da3), _plane(da3), _ptr(a2_hi), _ptr(a1_hi), _ptr(w3t), _ptr(w2t), _plane(w3t),
                                 _ptr(da2), _plane(da2), _ptr(da1), _plane(da1), batch, _ptr(frames), _ptr(idx),
-                                _ptr(gw), _ptr(gb), 32 * 256, 32, float(scale), _stream())
+                                _ptr(gw), _ptr(gb), 32 * 256, 32, float(scale), _ptr(ref), stride, _stream())
 
 
 def x3_conv_fwd(x, w, bias, out, batch, H, W, C, KH, KW, S, O, act=ACT_RELU):
@@ -585,15 +637,17 @@ def x3_conv1_wgrad_u8_whole(dy, frames, idx, gw, gb, batch, H, W, C, scale, slic
     """conv1 weight gradient (dy split, frames exact) by the whole-image kernel: conv1_wgrad_slices(batch) slab slices."""
     L = _L()
     L.pda_conv1_wgrad_u8_x3.argtypes = [_vp, ctypes.c_long, _vp, _vp, _vp, _vp] + [ctypes.c_int] * 4 + \
-        [ctypes.c_float, ctypes.c_long, ctypes.c_long, _vp]
+        [ctypes.c_float, ctypes.c_long, ctypes.c_long, _vp, ctypes.c_long, _vp]
     L.pda_conv1_wgrad_u8_x3.restype = None
+    (ref,), stride = _windows([frames])
     L.pda_conv1_wgrad_u8_x3(_ptr(dy), _plane(dy), _ptr(frames), _ptr(idx), _ptr(gw), _ptr(gb), batch, H, W, C,
-                            float(scale), slice_stride, bslice_stride, _stream())
+                            float(scale), slice_stride, bslice_stride, _ptr(ref), stride, _stream())
 
 
 def x3_conv_wgrad_u8(dy, frames, idx, gw, gb, batch, H, W, C, KH, KW, S, O, scale, ksplit=0, slice_stride=0,
                      bslice_stride=0):
     """conv1 weight gradient: dy split, frames exact (generic implicit GEMM, split-K slabs)."""
     assert ksplit == 0 or slice_stride >= O * C * KH * KW
+    _no_windows(frames, "the generic conv1 weight gradient")
     _X().pda_x3_conv_wgrad_u8(_ptr(dy), _plane(dy), _ptr(frames), _ptr(idx), _ptr(gw), _ptr(gb), batch, H, W, C, KH,
                               KW, S, O, float(scale), slice_stride, bslice_stride, int(ksplit), _stream())

@@ -51,6 +51,51 @@ def unpack_records(records, n, positions, state0s, state1s, tails, state_bytes, 
     tails[pos, :tail_floats] = tail
 
 
+def unpack_runs(records, n_runs, codec, counts, plane_base, trans_pos, planes, tails, ref0, refN, window, window_vals):
+    """Frame-deduplicated replay (parallel/csrc/frame_runs.h): copy the planes of n_runs run records to
+    planes[plane_base[r] ...] and their transitions to ring rows trans_pos[r] ... (mod len(tails)): tails, and the two
+    frame windows as plane indices ref0 / refN.  counts: [(num_planes, num_transitions)] per run, read by the host
+    from the records' headers; window (int32[4], may be None) receives window_vals = (rows, first row, ring length)."""
+    if n_runs == 0:
+        return
+    dev = planes.device
+    m = int(tails.shape[0])
+    if dev.type == "cuda":
+        if not native_available():
+            from . import native_error
+            raise RuntimeError("unpack_runs on a GPU needs the HIP library: " + native_error())
+        L = lib()
+        if not getattr(L, "_unpack_runs_ready", False):
+            i32, vp, lng = ctypes.c_int, ctypes.c_void_p, ctypes.c_long
+            L.pda_replay_unpack_runs.argtypes = [vp, lng, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp,
+                                                 i32, i32, i32, vp]
+            L.pda_replay_unpack_runs.restype = i32
+            L._unpack_runs_ready = True
+        pb = (ctypes.c_int * n_runs)(*[int(v) for v in plane_base])
+        tp = (ctypes.c_int * n_runs)(*[int(v) for v in trans_pos])
+        rc = L.pda_replay_unpack_runs(_p(records), int(records.stride(0)), int(n_runs), pb, tp, m, _p(planes),
+                                      int(planes.stride(0)), codec.plane_cap, codec.trans_cap, codec.tail_floats,
+                                      _p(tails), int(tails.stride(0)), _p(ref0), _p(refN),
+                                      _p(window) if window is not None else ctypes.c_void_p(0),
+                                      int(window_vals[0]), int(window_vals[1]), int(window_vals[2]), _stream(dev))
+        if rc != 0:
+            raise ValueError("pda_replay_unpack_runs refused its arguments (%d runs, plane stride %d)"
+                             % (n_runs, planes.stride(0)))
+        return
+    rec = records[:n_runs].numpy()
+    for r in range(n_runs):
+        pl, tl, o0, oN = codec.parse(rec[r])
+        n_p, n_t = counts[r]
+        assert (n_p, n_t) == (len(pl), len(tl))
+        planes[plane_base[r]:plane_base[r] + n_p] = torch.from_numpy(pl.copy())
+        pos = (torch.arange(n_t) + int(trans_pos[r])) % m
+        tails[pos, :codec.tail_floats] = torch.from_numpy(tl)
+        ref0[pos] = torch.from_numpy(o0) + int(plane_base[r])
+        refN[pos] = torch.from_numpy(oN) + int(plane_base[r])
+    if window is not None:
+        window[:3] = torch.tensor(list(window_vals[:3]), dtype=torch.int32)
+
+
 def gather_states(states, idx, out=None):
     """states (M, ...) -> (B, ...) rows at idx."""
     dev = states.device

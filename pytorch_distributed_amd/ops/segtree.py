@@ -81,6 +81,19 @@ class DeviceSumMinTree(object):
         L.pda_segtree_set_leaves(_p(self.sum), _p(self.min), _p(leaf_inds), _p(values), n, _s(stream))
         self.repair(leaf_inds, n)
 
+    def clear(self, leaf_inds):
+        """Empty leaves: no mass in the sum tree, +inf in the min tree (as never-written leaves are)."""
+        if int(leaf_inds.numel()) == 0:
+            return
+        leaf_inds = leaf_inds.to(self.device, torch.int32).contiguous()
+        li = leaf_inds.long()
+        self.sum[li] = 0.0
+        self.min[li] = float("inf")
+        if not self.native:
+            self._repair_cpu(leaf_inds)
+        else:
+            self.repair(leaf_inds)
+
     def repair(self, leaf_inds, n=None):
         """Recompute every ancestor of the given leaves (their values were already
         written, e.g. by the fused TD kernel)."""

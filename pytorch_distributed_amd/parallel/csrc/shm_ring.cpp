@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "mailbox.h"
+#include "frame_runs.h"
 
 namespace {
 
@@ -385,6 +386,20 @@ struct NStep {
     std::vector<char> has_q;
     std::vector<float> tail;
     uint64_t emitted = 0;
+    struct RunPacker* run = nullptr;     // frame-deduplicated records (frame_runs.h); null = one full record per transition
+};
+
+// The open run of one env: planes appended in stream order, the window states as offsets into them.
+struct RunPacker {
+    uint32_t plane_bytes, plane_stride, trans_stride, tail_floats;
+    int C, plane_cap, trans_cap;
+    uint64_t planes_off;
+    std::vector<char> rec;               // header | transition table | planes
+    int np = 0, nt = 0;
+    std::vector<int> s_off;              // window order -> first plane of that state in the open run
+    int placed = 0;                      // leading window states that are in the open run
+    uint64_t opened_ms = 0; uint32_t max_age_ms = 250;
+    uint64_t runs = 0, planes = 0, transitions = 0;
 };
 
 char* ns_state(NStep* N, int i) { return N->pool.data() + (size_t)N->s_slot[i] * N->state_stride; }
@@ -395,6 +410,10 @@ void ns_append_state(NStep* N, const void* st) {
         slot = N->s_slot[0];
         for (int i = 1; i < N->n_s; ++i) N->s_slot[i - 1] = N->s_slot[i];
         N->n_s -= 1;
+        if (N->run) {
+            for (int i = 1; i < N->cap_s; ++i) N->run->s_off[i - 1] = N->run->s_off[i];
+            if (N->run->placed > 0) N->run->placed -= 1;
+        }
     } else {
         // free slot = one not referenced by the window
         std::vector<char> used(N->cap_s, 0);
@@ -404,6 +423,95 @@ void ns_append_state(NStep* N, const void* st) {
     }
     std::memcpy(N->pool.data() + (size_t)slot * N->state_stride, st, N->state_bytes);
     N->s_slot[N->n_s++] = slot;
+}
+
+int ring_push_wait(void* ring, const void* s0, uint32_t n0, const void* s1, uint32_t n1, const void* s2, uint32_t n2,
+                   uint32_t timeout_ms) {
+    uint32_t waited_us = 0, delay = 10;
+    for (;;) {
+        int rc = pda_ring_push(ring, s0, n0, s1, n1, s2, n2, nullptr, 0);
+        if (rc == 1) return 1;
+        if (rc < 0) return -2;
+        if (waited_us / 1000 >= timeout_ms) return -1;      // ring stayed full: the learner is not draining
+        std::this_thread::sleep_for(std::chrono::microseconds(delay));
+        waited_us += delay;
+        if (delay < 2000) delay *= 2;
+    }
+}
+
+// ---- frame-deduplicated runs (frame_runs.h) ----
+// Send the open run (if it holds a transition) and start an empty one; the window states are re-placed by run_sync.
+int run_ship(NStep* N, void* ring, uint32_t timeout_ms) {
+    RunPacker* R = N->run;
+    int rc = 1;
+    if (R->nt > 0) {
+        PdaRunHeader* h = reinterpret_cast<PdaRunHeader*>(R->rec.data());
+        h->magic = PDA_RUN_MAGIC; h->num_planes = R->np; h->num_transitions = R->nt; h->window = R->C;
+        rc = ring_push_wait(ring, R->rec.data(), (uint32_t)R->planes_off, R->rec.data() + R->planes_off,
+                            (uint32_t)R->np * R->plane_stride, nullptr, 0, timeout_ms);
+        if (rc == 1) { R->runs += 1; R->planes += (uint64_t)R->np; R->transitions += (uint64_t)R->nt; }
+    }
+    R->np = 0; R->nt = 0; R->placed = 0;
+    return rc;
+}
+// Planes that window state i adds behind the states before it: 1 when it is the previous state slid by one frame
+// (and that one is the newest thing in the run), else all C.
+int run_need(NStep* N, int i) {
+    RunPacker* R = N->run;
+    if (i > 0 && R->s_off[i - 1] + R->C == R->np &&
+        std::memcmp(ns_state(N, i - 1) + R->plane_bytes, ns_state(N, i), (size_t)(R->C - 1) * R->plane_bytes) == 0)
+        return 1;
+    return R->C;
+}
+// Place every window state that is not in the open run yet; a run without room is sent first (a fresh run always
+// holds the whole window: plane_cap >= 2 * (C + nstep + 2)).
+int run_sync(NStep* N, void* ring, uint32_t timeout_ms) {
+    RunPacker* R = N->run;
+    while (R->placed < N->n_s) {
+        int i = R->placed;
+        int need = run_need(N, i);
+        if (R->np + need > R->plane_cap) {
+            int rc = run_ship(N, ring, timeout_ms);
+            if (rc < 0) return rc;
+            continue;                       // placed == 0 again
+        }
+        if (R->np == 0 && R->nt == 0) R->opened_ms = now_ms();
+        char* dst = R->rec.data() + R->planes_off + (size_t)R->np * R->plane_stride;
+        const char* src = ns_state(N, i);
+        if (need == 1) {
+            std::memcpy(dst, src + (size_t)(R->C - 1) * R->plane_bytes, R->plane_bytes);
+            R->s_off[i] = R->s_off[i - 1] + 1;
+        } else {
+            for (int c = 0; c < R->C; ++c)
+                std::memcpy(dst + (size_t)c * R->plane_stride, src + (size_t)c * R->plane_bytes, R->plane_bytes);
+            R->s_off[i] = R->np;
+        }
+        R->np += need;
+        R->placed += 1;
+    }
+    return 1;
+}
+int run_emit(NStep* N, void* ring, int first, int last_state, const float* tail, uint32_t timeout_ms) {
+    RunPacker* R = N->run;
+    if (R->nt >= R->trans_cap) {
+        int rc = run_ship(N, ring, timeout_ms);
+        if (rc < 0) return rc;
+    }
+    int rc = run_sync(N, ring, timeout_ms);
+    if (rc < 0) return rc;
+    char* e = R->rec.data() + sizeof(PdaRunHeader) + (size_t)R->nt * R->trans_stride;
+    std::memcpy(e, tail, 4u * R->tail_floats);
+    int32_t offs[2] = {R->s_off[first], R->s_off[last_state]};
+    std::memcpy(e + 4u * R->tail_floats, offs, 8);
+    R->nt += 1;
+    N->emitted += 1;
+    return 1;
+}
+// after a step: a run that has been open for max_age_ms goes out even if it is not full (fresh data for the learner)
+int run_age_check(NStep* N, void* ring, uint32_t timeout_ms) {
+    RunPacker* R = N->run;
+    if (R->nt > 0 && now_ms() - R->opened_ms >= R->max_age_ms) return run_ship(N, ring, timeout_ms);
+    return 1;
 }
 
 int ns_emit(NStep* N, void* ring, int first, int last_state, int term_idx, double ret, double gamma_sn,
@@ -417,18 +525,12 @@ int ns_emit(NStep* N, void* ring, int first, int last_state, int term_idx, doubl
         t[A + 2 * T + j] = N->terms[term_idx];
     }
     t[A + 3 * T] = (float)prio;
+    if (N->run) return run_emit(N, ring, first, last_state, t, timeout_ms);
     uint32_t tail_bytes = N->record_bytes - 2 * N->state_stride;
-    uint32_t waited_us = 0, delay = 10;
-    for (;;) {
-        int rc = pda_ring_push(ring, ns_state(N, first), N->state_stride, ns_state(N, last_state), N->state_stride,
-                               t, tail_bytes, nullptr, 0);
-        if (rc == 1) { N->emitted += 1; return 1; }
-        if (rc < 0) return -2;
-        if (waited_us / 1000 >= timeout_ms) return -1;      // ring stayed full: the learner is not draining
-        std::this_thread::sleep_for(std::chrono::microseconds(delay));
-        waited_us += delay;
-        if (delay < 2000) delay *= 2;
-    }
+    int rc = ring_push_wait(ring, ns_state(N, first), N->state_stride, ns_state(N, last_state), N->state_stride,
+                            t, tail_bytes, timeout_ms);
+    if (rc == 1) N->emitted += 1;
+    return rc;
 }
 
 }  // namespace
@@ -453,12 +555,56 @@ void* pda_nstep_create(int nstep, double gamma, int enable_per, uint32_t state_b
     N->tail.assign((record_bytes - 2 * state_stride) / 4 + 4, 0.f);
     return N;
 }
-void pda_nstep_destroy(void* h) { delete static_cast<NStep*>(h); }
+// The same assembler writing frame-deduplicated run records (frame_runs.h).  window: planes per state (C of a
+// [C, H, W] frame stack); the ring's payload must be pda_run_record_bytes(...).
+void* pda_nstep_create_dedup(int nstep, double gamma, int enable_per, uint32_t state_bytes, int window,
+                             int action_floats, int num_tasks, int plane_cap, int trans_cap, uint32_t max_age_ms) {
+    if (window < 1 || state_bytes % (uint32_t)window != 0) return nullptr;
+    uint32_t plane_bytes = state_bytes / (uint32_t)window;
+    if (plane_bytes % 16 != 0) return nullptr;          // a state is read as `window` planes at plane stride
+    if (plane_cap < 2 * (window + nstep + 2) || trans_cap < 2) return nullptr;
+    uint32_t tail_floats = (uint32_t)(action_floats + 3 * num_tasks + 1);
+    uint32_t state_stride = (state_bytes + 15u) / 16u * 16u;
+    NStep* N = static_cast<NStep*>(pda_nstep_create(nstep, gamma, enable_per, state_bytes, state_stride, action_floats,
+                                                    num_tasks, 2 * state_stride + 4 * tail_floats + 16));
+    if (!N) return nullptr;
+    RunPacker* R = new RunPacker();
+    R->plane_bytes = plane_bytes; R->plane_stride = pda_run_plane_stride(plane_bytes);
+    R->tail_floats = tail_floats; R->trans_stride = pda_run_trans_stride(tail_floats);
+    R->C = window; R->plane_cap = plane_cap; R->trans_cap = trans_cap;
+    R->planes_off = pda_run_planes_offset(tail_floats, (uint32_t)trans_cap);
+    R->rec.assign(pda_run_record_bytes(tail_floats, (uint32_t)trans_cap, plane_bytes, (uint32_t)plane_cap), 0);
+    R->s_off.assign(N->cap_s, 0);
+    R->max_age_ms = max_age_ms;
+    N->run = R;
+    return N;
+}
+uint64_t pda_run_record_size(int action_floats, int num_tasks, int trans_cap, uint32_t plane_bytes, int plane_cap) {
+    return pda_run_record_bytes((uint32_t)(action_floats + 3 * num_tasks + 1), (uint32_t)trans_cap, plane_bytes,
+                                (uint32_t)plane_cap);
+}
+// Send the open run now (tests, shutdown).  Returns 1, or -1 / -2 as pda_nstep_push.
+int pda_nstep_ship(void* h, void* ring, uint32_t timeout_ms) {
+    NStep* N = static_cast<NStep*>(h);
+    return N->run ? run_ship(N, ring, timeout_ms) : 1;
+}
+// out[0..2] = runs, planes, transitions sent so far
+void pda_nstep_run_stats(void* h, uint64_t* out) {
+    NStep* N = static_cast<NStep*>(h);
+    out[0] = out[1] = out[2] = 0;
+    if (N->run) { out[0] = N->run->runs; out[1] = N->run->planes; out[2] = N->run->transitions; }
+}
+void pda_nstep_destroy(void* h) {
+    NStep* N = static_cast<NStep*>(h);
+    delete N->run;
+    delete N;
+}
 uint64_t pda_nstep_emitted(void* h) { return static_cast<NStep*>(h)->emitted; }
 
 void pda_nstep_reset(void* h, const void* state) {
     NStep* N = static_cast<NStep*>(h);
     N->n_s = 0; N->n_o = 0;
+    if (N->run) N->run->placed = 0;         // (what the open run already holds stays; the new episode's states follow)
     ns_append_state(N, state);
 }
 
@@ -491,7 +637,9 @@ int pda_nstep_push(void* h, void* ring, const float* action, double reward, cons
         prio = ret + gamma_sn * N->maxqs[N->n_o - 1] - N->qs[0];
         if (prio < 0) prio = -prio;
     }
-    return ns_emit(N, ring, 0, N->n_s - 2, N->n_o - 2, ret, gamma_sn, prio, timeout_ms);
+    int rc = ns_emit(N, ring, 0, N->n_s - 2, N->n_o - 2, ret, gamma_sn, prio, timeout_ms);
+    if (rc > 0 && N->run) { int a = run_age_check(N, ring, timeout_ms); if (a < 0) return a; }
+    return rc;
 }
 
 // Episode ended: emit the one closing transition (see the header comment).
@@ -514,7 +662,9 @@ int pda_nstep_flush(void* h, void* ring, double maxq_last, int has_maxq, uint32_
         prio = ret + gamma_sn * maxq_last - N->qs[first];
         if (prio < 0) prio = -prio;
     }
-    return ns_emit(N, ring, first, N->n_s - 1, N->n_o - 1, ret, gamma_sn, prio, timeout_ms);
+    int rc = ns_emit(N, ring, first, N->n_s - 1, N->n_o - 1, ret, gamma_sn, prio, timeout_ms);
+    if (rc > 0 && N->run) { int a = run_age_check(N, ring, timeout_ms); if (a < 0) return a; }
+    return rc;
 }
 
 // ---- inference mailbox (protocol in mailbox.h) ------------------------------------------

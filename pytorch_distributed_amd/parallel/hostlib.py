@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "shm_ring.cpp")
-HEADERS = [os.path.join(_HERE, "csrc", "mailbox.h")]
+HEADERS = [os.path.join(_HERE, "csrc", "mailbox.h"), os.path.join(_HERE, "csrc", "frame_runs.h")]
 LIB_PATH = os.path.join(_HERE, "libpda_host.so")
 _LIB = None
 
@@ -76,6 +76,14 @@ def lib():
         dbl = ctypes.c_double
         L.pda_nstep_create.restype = vp
         L.pda_nstep_create.argtypes = [i32, dbl, i32, u32, u32, i32, i32, u32]
+        L.pda_nstep_create_dedup.restype = vp
+        L.pda_nstep_create_dedup.argtypes = [i32, dbl, i32, u32, i32, i32, i32, i32, i32, u32]
+        L.pda_run_record_size.restype = u64
+        L.pda_run_record_size.argtypes = [i32, i32, i32, u32, i32]
+        L.pda_nstep_ship.restype = i32
+        L.pda_nstep_ship.argtypes = [vp, vp, u32]
+        L.pda_nstep_run_stats.restype = None
+        L.pda_nstep_run_stats.argtypes = [vp, vp]
         L.pda_nstep_destroy.restype = None
         L.pda_nstep_destroy.argtypes = [vp]
         L.pda_nstep_emitted.restype = u64

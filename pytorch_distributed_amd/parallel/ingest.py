@@ -43,6 +43,61 @@ class TransitionCodec(object):
         return t
 
 
+class RunCodec(object):
+    """Layout of a frame-deduplicated run record (csrc/frame_runs.h): header | transition table | planes.
+    A state [C, ...] is `window` = C planes of plane_bytes each."""
+
+    HEADER = 64
+    MAGIC = 0x52554E31
+
+    def __init__(self, state_shape, action_shape, num_tasks, plane_cap=96, trans_cap=None):
+        self.state_shape = tuple(state_shape)
+        if len(self.state_shape) < 2:
+            raise ValueError("frame-deduplicated replay needs [C, ...] frame stacks, not states of shape %r"
+                             % (self.state_shape,))
+        self.window = int(self.state_shape[0])
+        self.plane_bytes = int(np.prod(self.state_shape[1:]))
+        if self.plane_bytes % 16:
+            raise ValueError("frame-deduplicated replay needs planes of a multiple of 16 bytes (got %d)" % self.plane_bytes)
+        self.plane_stride = self.plane_bytes
+        self.tail_floats = int(action_shape) + 3 * int(num_tasks) + 1
+        self.trans_stride = _round_up(4 * self.tail_floats + 8, 16)
+        self.plane_cap = int(plane_cap)
+        self.trans_cap = int(trans_cap or plane_cap)
+        self.planes_offset = self.HEADER + self.trans_cap * self.trans_stride
+        self.record_bytes = self.planes_offset + self.plane_cap * self.plane_stride
+
+    def header(self, rec):
+        """(num_planes, num_transitions) of one record (uint8 numpy row)."""
+        h = rec[:16].view(np.uint32)
+        if int(h[0]) != self.MAGIC:
+            raise ValueError("not a run record (magic %#x)" % int(h[0]))
+        return int(h[1]), int(h[2])
+
+    def parse(self, rec):
+        """-> (planes uint8 [np, plane_bytes], tails f32 [nt, tail_floats], off0 int32 [nt], offN int32 [nt])"""
+        n_p, n_t = self.header(rec)
+        table = rec[self.HEADER:self.HEADER + n_t * self.trans_stride].reshape(n_t, self.trans_stride)
+        tails = table[:, :4 * self.tail_floats].copy().view(np.float32)
+        offs = table[:, 4 * self.tail_floats:4 * self.tail_floats + 8].copy().view(np.int32)
+        planes = rec[self.planes_offset:self.planes_offset + n_p * self.plane_stride].reshape(n_p, self.plane_stride)
+        return planes, tails, offs[:, 0].copy(), offs[:, 1].copy()
+
+    def pack(self, planes, tails, off0, offN):
+        """The inverse of parse (Python producers, tests): -> uint8 [record_bytes]."""
+        n_p, n_t = len(planes), len(tails)
+        assert n_p <= self.plane_cap and n_t <= self.trans_cap
+        rec = np.zeros(self.record_bytes, dtype=np.uint8)
+        rec[:16].view(np.uint32)[:] = [self.MAGIC, n_p, n_t, self.window]
+        table = rec[self.HEADER:self.HEADER + n_t * self.trans_stride].reshape(n_t, self.trans_stride)
+        table[:, :4 * self.tail_floats] = np.ascontiguousarray(tails, dtype=np.float32).reshape(n_t, -1).view(np.uint8)
+        offs = np.stack([np.asarray(off0, dtype=np.int32), np.asarray(offN, dtype=np.int32)], axis=1)
+        table[:, 4 * self.tail_floats:4 * self.tail_floats + 8] = offs.view(np.uint8)
+        rec[self.planes_offset:self.planes_offset + n_p * self.plane_stride] = \
+            np.ascontiguousarray(planes, dtype=np.uint8).reshape(-1)
+        return rec
+
+
 class ShmRing(object):
     def __init__(self, num_slots, payload_bytes):
         L = hostlib.lib()

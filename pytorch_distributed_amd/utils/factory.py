@@ -13,6 +13,7 @@ from ..envs.synthetic_env import SyntheticAtariEnv, make_synthetic_env
 from ..envs.pendulum_env import PendulumEnv, ChainEnv, CountingEnv
 from ..memories.shared_memory import SharedMemory
 from ..memories.device_memory import DeviceMemory
+from ..memories.dedup_memory import DedupDeviceMemory
 from ..models.dqn_cnn_model import DqnCnnModel
 from ..models.dqn_mlp_model import DqnMlpModel
 from ..models.ddpg_mlp_model import DdpgMlpModel
@@ -39,6 +40,8 @@ MemoriesDict = {"shared": SharedMemory,         # host shm ring, uniform
                 "shared-per": SharedMemory,     # host shm ring + sum/min tree
                 "device": DeviceMemory,         # HBM-resident ring, uniform
                 "device-per": DeviceMemory,     # HBM-resident ring + HIP segment tree
+                "device-dedup": DedupDeviceMemory,      # HBM-resident, every frame stored once (memories/dedup_memory.py)
+                "device-dedup-per": DedupDeviceMemory,  # ... + HIP segment tree
                 "none": None}
 
 ModelsDict = {"dqn-cnn": DqnCnnModel,

@@ -256,6 +256,12 @@ class MemoryParams(Params):
         self.ingest_ring_slots = 4096   # transitions buffered in the shm ring
         self.ingest_chunk = 256         # max transitions moved to HBM per drain
         self.ingest_device_slabs = 32   # device-side chunks in flight between their H2D copy and the unpack kernel
+        # frame-deduplicated replay (memory_type "device-dedup[-per]", memories/dedup_memory.py)
+        self.dedup_plane_cap = 96       # planes per run record (a run restart re-sends nstep + window + 1 planes)
+        self.dedup_plane_slack = 1.25   # planes kept per transition row of the ring
+        self.dedup_ring_mb = 64         # shm ring between the actors and the learner
+        self.dedup_chunk_runs = 8       # run records per H2D copy (<= 16)
+        self.dedup_max_age_ms = 250     # a run that is not full goes out after this long
 
 
 class ModelParams(Params):

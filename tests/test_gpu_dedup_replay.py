@@ -1,0 +1,112 @@
+"""Frame-deduplicated replay on the GPU (memories/dedup_memory.py): the run-unpack kernel against what the actors
+sent, and the learner step reading frame windows of the plane store (ops/nn.py FrameWindows, csrc/nature_cnn.h
+frame_index) against the same step reading rows of full frame stacks -- bit for bit, both engines, small and large
+batch (the stack kernels and the whole-image conv1 kernels)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def native():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from pytorch_distributed_amd import ops
+    ops.require_native()
+
+
+def options(memory_type, size, batch=32, precision="fp32", **mp):
+    from pytorch_distributed_amd.launcher import prepare_options
+    from pytorch_distributed_amd.utils.options import Options
+    ov = {"device": "cuda", "memory_type": memory_type, "memory_params.memory_size": size,
+          "memory_params.replay_device": "cuda", "agent_params.batch_size": batch, "precision": precision,
+          "graph_steps": 1}
+    ov.update({"memory_params." + k: v for k, v in mp.items()})
+    return prepare_options(Options(config=2, overrides=ov))
+
+
+def test_unpack_kernel_holds_what_the_actors_sent():
+    from test_dedup_memory import check_rows, play
+    from pytorch_distributed_amd.agents.nstep import NStepAssembler, make_feeder
+    from pytorch_distributed_amd.utils.factory import MemoriesDict
+    opt = options("device-dedup-per", 1024)
+    m = MemoriesDict[opt.memory_type](opt.memory_params)
+    rng = np.random.RandomState(0)
+    f = make_feeder(m, 5, 0.99, enable_per=True)
+    m.attach("cuda")
+    expected = []
+    for _ in range(6):
+        expected += play(f, rng, 6, 50, NStepAssembler(5, 0.99, enable_per=True), per=True)
+        for _ in range(200):
+            m.drain()
+            torch.cuda.synchronize()
+            if m.trans_linear == len(expected):
+                break
+    assert m.trans_linear == len(expected) > 300
+    n = min(len(expected), 1024)
+    lin = list(range(len(expected) - n, len(expected)))
+
+    class Cpu(object):          # check_rows reads through _gather
+        def _gather(self, idx):
+            return tuple(t.cpu() for t in m._gather(idx.cuda()))
+    check_rows(Cpu(), [j % 1024 for j in lin], [expected[j] for j in lin])
+    w = m.window_dev.cpu().tolist()
+    assert tuple(w[:3]) == m.window() == (n, (len(expected) - n) % 1024, 1024)
+    # initial priorities went into the tree
+    pr = torch.tensor([p for _, p in expected[-n:]], dtype=torch.float32)
+    want = (pr.abs() + m.priority_eps) ** m.priority_exponent
+    got = m.tree.get(torch.tensor([j % 1024 for j in lin], device="cuda")).cpu()
+    assert torch.allclose(got, want, rtol=1e-5)
+    m.close()
+
+
+@pytest.mark.parametrize("precision,batch,per", [("fp32", 32, False), ("bf16", 32, True), ("fp32", 512, False),
+                                                 ("bf16", 512, False)])
+def test_step_on_frame_windows_equals_step_on_full_stacks(precision, batch, per):
+    from pytorch_distributed_amd.ops.dqn_engine import DqnNativeCore
+    from pytorch_distributed_amd.utils.factory import MemoriesDict, ModelsDict
+    n = 1024
+    kind = "-per" if per else ""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    s = torch.randint(0, 256, (n + 1, 4, 84, 84), dtype=torch.uint8, device="cuda", generator=g)
+    a = torch.randint(0, 6, (n, 1), device="cuda", generator=g)
+    r = torch.randn(n, 1, device="cuda", generator=g).clamp_(-1, 1)
+    t = (torch.rand(n, 1, device="cuda", generator=g) < 0.05).float()
+    pr = torch.rand(n, device="cuda", generator=g) + 0.05
+    flats = []
+    for memory_type, mp in (("device" + kind, {}), ("device-dedup" + kind, {"dedup_plane_slack": 8.5})):
+        opt = options(memory_type, n, batch, precision, **mp)
+        memory = MemoriesDict[opt.memory_type](opt.memory_params)
+        memory.attach("cuda")
+        memory.feed_batch(s[:-1], a, r, torch.full((n, 1), 0.95, device="cuda"), s[1:], t, priorities=pr)
+        assert memory.size == n
+        torch.manual_seed(3)
+        model = ModelsDict[opt.model_type](opt.model_params, opt.norm_val, opt.state_shape, opt.action_space, 1).cuda()
+        target = ModelsDict[opt.model_type](opt.model_params, opt.norm_val, opt.state_shape, opt.action_space, 1).cuda()
+        core = DqnNativeCore(opt, model, target, memory)
+        assert core.dedup == ("dedup" in memory_type)
+        for _ in range(6):
+            core.step()
+        torch.cuda.synchronize()
+        flats.append((core.flat_params().clone(), core.engine.idx.clone(), core.engine.td.clone()))
+        memory.close()
+    assert torch.equal(flats[0][1], flats[1][1])        # the same rows were drawn
+    assert torch.equal(flats[0][2], flats[1][2])        # ... gave the same TD errors
+    assert torch.equal(flats[0][0], flats[1][0])        # ... and the same parameters after six updates
+
+
+def test_synthetic_fill_and_window_draw():
+    from pytorch_distributed_amd.utils.factory import MemoriesDict
+    opt = options("device-dedup", 4096)
+    m = MemoriesDict[opt.memory_type](opt.memory_params)
+    m.attach("cuda")
+    m.fill_synthetic(4096, nstep=5, num_actions=6)
+    assert m.window_dev.cpu().tolist()[:3] == [4096, 0, 4096]
+    s0, a, r, g, s1, t = m.sample(16)
+    assert s0.shape == (16, 4, 84, 84) and s0.dtype == torch.uint8 and float(a.max()) <= 5
+    # plane p + 1 of s0's window is plane p of the window one step later
+    i = torch.arange(8, device="cuda", dtype=torch.int32)
+    assert torch.equal(m.states(m.ref0, i)[1:, 0], m.states(m.ref0, i)[:-1, 1])
+    m.close()
