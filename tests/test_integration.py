@@ -79,6 +79,23 @@ def test_device_replay_per_batched_inference_and_finetune(tmp_root):
     assert all(torch.equal(a[k], b[k]) for k in a)      # lr=0: weights carried over unchanged
 
 
+def test_frame_deduplicated_replay_whole_job(tmp_root):
+    """memory_type device-dedup-per (host tensors here): the actors' n-step assemblers send runs of planes, the learner
+    samples frame windows of its plane ring (memories/dedup_memory.py); 2 envs per actor = 4 interleaved streams."""
+    import json
+    opt = opts(4, tmp_root, num_actors=2, num_envs_per_actor=2, timestamp="dedup", memory_type="device-dedup-per",
+               **{"agent_params.steps": 25, "agent_params.learn_start": 40, "agent_params.batch_size": 8,
+                  "memory_params.memory_size": 256, "memory_params.dedup_plane_cap": 32,
+                  "memory_params.dedup_max_age_ms": 2000, "memory_params.dedup_chunk_runs": 2})
+    from pytorch_distributed_amd.utils.factory import MemoriesDict
+    assert MemoriesDict[opt.memory_type].__name__ == "DedupDeviceMemory"
+    sup = run(opt)
+    check_common(opt, sup, 25)
+    with open(os.path.join(opt.log_dir, "replay_stats.json")) as f:
+        st = json.load(f)
+    assert st["transitions"] >= 40 and st["planes_per_transition"] < 3.0 and st["rows_in_window"] > 0
+
+
 def test_supervisor_restarts_dead_actor(tmp_root):
     opt = opts(6, tmp_root, inject_fault="actor:1@15", **{"agent_params.steps": 150})
     sup = run(opt)
