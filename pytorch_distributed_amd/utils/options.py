@@ -33,6 +33,7 @@ CONFIGS = [
     ["dqn",  "chain",     "chain",     "shared",     "dqn-mlp"],   # 6 tiny learnable task for sanity tests
     ["ddpg", "pendulum",  "pendulum",  "device",     "ddpg-mlp"],  # 7 DDPG with HBM replay + native kernels
     ["dqn",  "synthetic", "minipong",  "device",     "dqn-cnn"],   # 8 row 2 on the built-in pixel Pong (envs/minipong.py)
+    ["dqn",  "synthetic", "pong",      "device-dedup-per", "dqn-cnn"],   # 9 row 4 on frame-deduplicated replay (memories/dedup_memory.py)
 ]
 
 # per-config presets applied after the defaults (dotted keys reach nested params)
@@ -44,6 +45,10 @@ PRESETS = {
     # little as with the native one: see row 7 and BASELINE.md "DDPG recipe".
     3: {"num_actors": 8, "agent_params.nstep": 5},
     4: {"num_actors": 256, "actor_inference": "batched", "memory_params.memory_size": 2 * 1024 * 1024,
+        "memory_params.enable_per": True, "agent_params.nstep": 5},
+    # 9 = row 4 with every frame stored once: 2 M transitions in 18.5 GB of planes instead of 113 GB of frame stacks,
+    # a seventh of the ingest bytes (whole job, 256 envs: 948 k env frames/s + 8.1 k updates/s against 856 k + 7.8 k)
+    9: {"num_actors": 256, "actor_inference": "batched", "memory_params.memory_size": 2 * 1024 * 1024,
         "memory_params.enable_per": True, "agent_params.nstep": 5},
     5: {"num_actors": 256, "actor_inference": "batched", "memory_params.memory_size": 1024 * 1024,
         "memory_params.enable_per": True, "agent_params.batch_size": 4096},
