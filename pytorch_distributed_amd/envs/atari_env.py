@@ -10,7 +10,6 @@ factory registers) then falls back to SyntheticAtariEnv with a warning so that
 `python main.py` stays runnable on a box without ROMs.
 """
 import warnings
-from collections import deque
 
 import numpy as np
 
@@ -64,44 +63,62 @@ def _open_ale(game):
 
 
 class AtariEnv(Env):
-    """`ale` may be any object with the ALEInterface methods used here (setInt/setFloat/setBool, loadROM,
+    """The wrapper is three pieces: a frame stack kept as ONE [C, H, W] uint8 array that is shifted in place (the
+    observation handed out is a copy of it: no per-step list of arrays, no np.stack), `_repeat` = the action-repeat /
+    frame-max unit, and the life bookkeeping that turns a lost life into a training-time terminal followed by a
+    no-op "soft reset".
+
+    `ale` may be any object with the ALEInterface methods used here (setInt/setFloat/setBool, loadROM,
     getMinimalActionSet, act, game_over, lives, reset_game, getScreenGrayscale, getScreenRGB): the tests drive
     the wrapper with a scripted one (tests/test_atari_env.py), production passes None and opens the emulator."""
 
+    REPEAT = 4              # emulator frames per agent step (reference atari_env.py:95)
+    POOLED = 2              # ... of which the last POOLED are max-pooled into the new observation plane
+    MAX_NOOP_STARTS = 30    # reference atari_env.py:123
+
     def __init__(self, args, process_ind=0, num_envs_per_process=1, ale=None):
+        self._stack = None
         super().__init__(args, process_ind, num_envs_per_process)
         assert self.num_envs_per_process == 1
-        if ale is None:
-            self.ale, rom = _open_ale(self.game)
-        else:
-            self.ale, rom = ale, self.game
-        self.ale.setInt("random_seed", self.seed)
-        self.ale.setInt("max_num_frames", self.early_stop)
-        self.ale.setFloat("repeat_action_probability", 0)   # sticky actions off
-        self.ale.setInt("frame_skip", 0)
-        self.ale.setBool("color_averaging", False)
+        self.ale, rom = (ale, self.game) if ale is not None else _open_ale(self.game)
+        for setter, key, value in ((self.ale.setInt, "random_seed", self.seed),
+                                   (self.ale.setInt, "max_num_frames", self.early_stop),
+                                   (self.ale.setFloat, "repeat_action_probability", 0),     # sticky actions off
+                                   (self.ale.setInt, "frame_skip", 0),
+                                   (self.ale.setBool, "color_averaging", False)):
+            setter(key, value)
         self.ale.loadROM(rom)                               # after the options
-        actions = self.ale.getMinimalActionSet()
-        self.actions = dict(enumerate(actions))
+        self.actions = dict(enumerate(self.ale.getMinimalActionSet()))
         self.lives = 0
-        self.just_died = False      # lost a life but the game is not over
-        self.exp_state1 = deque(maxlen=self.state_cha)
-        self._reset_experience()
+        self._soft_reset_due = False        # a life was lost in training mode and the game goes on
+        self._stack = np.zeros((self.state_cha, self.state_hei, self.state_wid), dtype=np.uint8)
+        self._pool = np.zeros((self.POOLED, self.state_hei, self.state_wid), dtype=np.uint8)
 
-    def _reset_experience(self):
-        self.exp_state0 = None
-        self.exp_action = None
-        self.exp_reward = None
-        self.exp_terminal1 = None
-        if isinstance(getattr(self, "exp_state1", None), deque):
-            for _ in range(self.state_cha):
-                self.exp_state1.append(np.zeros((self.state_hei, self.state_wid), dtype=np.uint8))
+    # ---- the reference's attribute names, for code and tests written against them ----
+    @property
+    def just_died(self):
+        return self._soft_reset_due
 
+    @property
+    def exp_state1(self):
+        return self._stack
+
+    @exp_state1.setter
+    def exp_state1(self, value):            # Env._reset_experience assigns None: the stack is cleared instead
+        if self._stack is not None:
+            self._stack[:] = 0 if value is None else value
+
+    # ---- frames ----
     def _capture_ale(self):
         return resize_bilinear_u8(self.ale.getScreenGrayscale().squeeze(), self.state_hei, self.state_wid)
 
+    def _push_plane(self, plane):
+        s = self._stack
+        s[:-1] = s[1:]
+        s[-1] = plane
+
     def _preprocess_state(self, state):
-        return np.stack(state, axis=0)
+        return np.array(state, dtype=np.uint8, copy=True)
 
     def _preprocess_action(self, action):
         return np.asarray(action).reshape(self.action_shape)
@@ -140,40 +157,51 @@ class AtariEnv(Env):
         except Exception:
             pass
 
+    # ---- one agent step ----
+    def _repeat(self, ale_action):
+        """REPEAT emulator frames of one action, stopping at game over -> (summed reward, game over).  The screens of
+        the last POOLED repeats land in self._pool (a repeat that never ran leaves its plane black)."""
+        self._pool[:] = 0
+        total, over = 0.0, False
+        first_pooled = self.REPEAT - self.POOLED
+        for k in range(self.REPEAT):
+            total += self.ale.act(ale_action)
+            if k >= first_pooled:
+                self._pool[k - first_pooled] = self._capture_ale()
+            over = bool(self.ale.game_over())
+            if over:
+                break
+        return total, over
+
     def step(self, action):
         self.exp_action = self._preprocess_action(action)
-        frames = np.zeros((2, self.state_hei, self.state_wid), dtype=np.uint8)
-        self.exp_reward = 0.0
-        self.exp_terminal1 = False
-        ale_action = self.actions.get(int(np.asarray(action).reshape(-1)[0]))
-        for t in range(4):          # repeat 4x, max-pool the last two frames
-            self.exp_reward += self.ale.act(ale_action)
-            if t >= 2:
-                frames[t - 2] = self._capture_ale()
-            self.exp_terminal1 = self.ale.game_over()
-            if self.exp_terminal1:
-                break
-        self.exp_state1.append(np.maximum(frames[0], frames[1]))
-        if self.training:           # loss of life is terminal while training
-            lives = self.ale.lives()
-            if 0 < lives < self.lives:
-                self.just_died = not self.exp_terminal1
-                self.exp_terminal1 = True
-            self.lives = lives
+        index = int(np.asarray(action).reshape(-1)[0])
+        self.exp_reward, over = self._repeat(self.actions.get(index))
+        self._push_plane(self._pool.max(axis=0))
+        terminal = over
+        if self.training:           # a lost life ends the episode for the learner, not for the emulator
+            now = self.ale.lives()
+            if 0 < now < self.lives:
+                self._soft_reset_due = not over
+                terminal = True
+            self.lives = now
+        self.exp_terminal1 = terminal
         return self._get_experience()
 
     def reset(self):
-        if self.just_died:
-            self.just_died = False
-            self.ale.act(0)         # no-op after a lost life
+        if self._soft_reset_due:    # the game goes on: one no-op, the frame stack is kept
+            self._soft_reset_due = False
+            self.ale.act(0)
         else:
             self._reset_experience()
             self.ale.reset_game()
-            for _ in range(self.rng.randint(30)):   # up to 30 no-ops
-                self.ale.act(0)
+            noops = int(self.rng.randint(self.MAX_NOOP_STARTS))
+            while noops > 0:
+                noops -= 1
+                self.ale.act(0)     # raw action 0 is the no-op
                 if self.ale.game_over():
                     self.ale.reset_game()
-        self.exp_state1.append(self._capture_ale())
+        self._push_plane(self._capture_ale())
         self.lives = self.ale.lives()
         return self._get_experience()
 
