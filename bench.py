@@ -86,6 +86,10 @@ def parse_args(argv=None):
     ap.add_argument("--node-envs-per-actor", type=int, default=4,
                     help="envs per actor process (pipelined requests); 2 -> 4 lifts the env side from ~460 k to ~780 k "
                          "frames/s on 16 host cores while the learner keeps its rate (profiles/r3_node_learner_loop.txt)")
+    ap.add_argument("--node-memory", default="device-dedup",
+                    help="replay kind of the --node job: device-dedup (every frame stored once: 1.11 planes = 7.9 KB per "
+                         "transition in the job instead of 56.5 KB; 307 s soak profiles/r3_node_soak_dedup_3M_steps.json) "
+                         "| device (both frame stacks in full) | config (what the options row names)")
     ap.add_argument("--node-timeout", type=float, default=240.0)
     ap.add_argument("--ddpg", default="auto", choices=["auto", "on", "off"],
                     help="also time the Distributed-DDPG learner step (config 7 shapes: 3-dim obs, 1-dim action, batch "
@@ -189,6 +193,10 @@ def run_node_job(a, precision, device):
            "--steps", str(a.node_steps), "--actors", str(a.node_actors),
            "--envs-per-actor", str(a.node_envs_per_actor), "--precision", precision,
            "--device", "cuda" if str(device).startswith("cuda") else "cpu"]
+    if a.node_memory != "config" and a.config in (2, 8):
+        cmd += ["--set", "memory_type=%s" % a.node_memory]
+    elif a.node_memory != "config" and a.config in (4, 5, 9):
+        cmd += ["--set", "memory_type=%s-per" % a.node_memory]
     try:
         env = dict(os.environ)
         env["PDA_LEARNER_PROF"] = "1"       # where the in-job learner's time goes (agents/learners.py _LoopProfile)
@@ -207,7 +215,7 @@ def run_node_job(a, precision, device):
                         "learner_updates_per_sec_steady", "env_frames_per_sec_mean", "env_frames_per_sec_peak",
                         "actor_steps_per_sec_mean", "inference", "exitcodes", "actor_restarts", "env", "memory",
                         "learner_updates_per_sec_windows", "env_frames_per_sec_windows", "logger_window_s",
-                        "learner_loop_profile")
+                        "learner_loop_profile", "replay_stats")
                 d = {k: d.get(k) for k in keep}
                 d["env_frames_per_sec"] = d.pop("env_frames_per_sec_mean")
                 d["learner_updates_per_sec_in_job"] = d.pop("learner_updates_per_sec_steady")

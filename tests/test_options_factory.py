@@ -69,7 +69,10 @@ def test_factory_names_match_reference():
         assert isinstance(getattr(factory, name), dict), name
     assert set(factory.ActorsDict) == {"dqn", "ddpg"}
     assert {"atari", "synthetic", "pendulum"} <= set(factory.EnvsDict)
-    assert {"shared", "none", "device", "device-per"} <= set(factory.MemoriesDict)
+    assert {"shared", "none", "device", "device-per", "device-dedup", "device-dedup-per"} <= set(factory.MemoriesDict)
+    o9 = Options(config=9, overrides={"device": "cpu"})     # Ape-X row on frame-deduplicated replay
+    assert o9.memory_type == "device-dedup-per" and o9.memory_params.enable_per
+    assert o9.memory_params.memory_size == 2 * 1024 * 1024 and o9.memory_params.dedup_plane_cap == 96
     assert {"dqn-cnn", "dqn-mlp", "ddpg-mlp"} == set(factory.ModelsDict)
     assert factory.MemoriesDict["none"] is None
 
