@@ -196,8 +196,10 @@ class Params(object):
         self.force_dp = False               # run the data-parallel step program even with one learner (rehearsal)
         self.engine_knobs = {}              # tuning knobs of the native engines (ops/knobs.py: split-K targets, DP wire
                                             # format / all-reduce / graph mode, ...); `engine_knobs.<name>=<value>`
-        self.graph_steps = 5                # native DQN learner, HBM replay, one rank: updates per hipGraph replay (the
-                                            # learner runs up to graph_steps - 1 updates ahead of its step counter)
+        self.graph_steps = 10               # native DQN learner, HBM replay, one rank: updates per hipGraph replay (the
+                                            # learner runs up to graph_steps - 1 updates ahead of its step counter).
+                                            # 5 / 10 / 25 / 50: 10.49 / 10.59 / 10.56 / 10.46 k updates/s alone (bf16
+                                            # 13.35 / 13.65 / 13.74 / 13.56), 9.79 / 9.89 / 9.81 k inside the job
 
         # prefix for saving models&logs
         self.root_dir = overrides.get("root_dir", os.getcwd())

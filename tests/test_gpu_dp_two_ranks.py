@@ -43,7 +43,7 @@ def test_two_rank_dp_bench_keeps_ranks_identical():
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_two_rank_dp_with_the_peer_allreduce_in_one_graph(precision):
     """Same rehearsal with the xGMI peer all-reduce kernel (hipIpc-mapped regions, ops/csrc/peer_allreduce.hip):
-    nothing host-driven is left in the step, so five whole data-parallel updates -- collectives included -- replay as
+    nothing host-driven is left in the step, so ten whole data-parallel updates -- collectives included -- replay as
     ONE hipGraph even though the process group is gloo."""
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PDA_DP_GRAPH", "PDA_DP_ALLREDUCE"):
@@ -71,7 +71,7 @@ def test_two_rank_dp_with_the_peer_allreduce_in_one_graph(precision):
     cu = res["dp_comm_us"]
     assert cu["steps"] == 20 and cu["allreduce_tail_us"] > 0 and cu["allreduce_head_us"] > 0
     assert cu["exposed_tail_us"] >= 0 and cu["exposed_head_us"] >= 0 and cu["step_us"] > cu["allreduce_tail_us"]
-    assert res["config"]["steps_per_graph"] == 5
+    assert res["config"]["steps_per_graph"] == 10
     assert res["dp_param_max_abs_diff_across_ranks"] == 0.0
     assert res["ranks_distinct"] is True
     assert res["final_loss"] == res["final_loss"] and res["value"] > 0
