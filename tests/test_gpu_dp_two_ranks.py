@@ -100,3 +100,23 @@ def test_eight_rank_dp_step_on_one_card():
     assert res["dp_param_max_abs_diff_across_ranks"] == 0.0 and res["dp_allreduce_errors"] == 0
     assert res["rccl_ranks"] == 8 and res["ranks_distinct"] is True and res["rank_id_min_max_sum"] == [0, 7, 28]
     assert res["final_loss"] == res["final_loss"] and res["value"] > 0
+
+
+@pytest.mark.gpu
+def test_two_rank_dp_on_frame_deduplicated_prioritized_replay():
+    """Config 9's combination in the same rehearsal: every rank samples frame windows of its own plane ring
+    (memories/dedup_memory.py) through its own sum tree; the data-parallel step is unchanged."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PDA_DP_GRAPH", "PDA_DP_ALLREDUCE"):
+        env.pop(k, None)
+    env["PDA_BENCH_FAULTHANDLER"] = "100"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5",
+           "--backend", "gloo", "--share-gpu", "--replay", "4096", "--min-time", "0", "--precision", "fp32",
+           "--allreduce", "peer", "--launch-timeout", "100", "--config", "4", "--memory-type", "device-dedup-per",
+           "--node", "off", "--ddpg", "off", "--extras", "off"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=115)
+    assert out.returncode == 0, out.stderr.decode(errors="replace")[-2000:]
+    res = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 2 and "frame-deduplicated" in res["config"]["replay_kind"]
+    assert res["dp_param_max_abs_diff_across_ranks"] == 0.0 and res["dp_allreduce_errors"] == 0
+    assert res["final_loss"] == res["final_loss"] and res["value"] > 0
