@@ -125,8 +125,15 @@ class NativeFeeder(object):
         if not self.h:
             raise ValueError("n-step assembler: inconsistent record layout")
         self._act = np.zeros(c.action_shape, dtype=np.float32)
+        # per-step constants of push(): what the actor loop would otherwise re-derive for every env step (this object
+        # is built inside the actor process, so the ring's mapping and these addresses stay put)
+        self._act_ptr = self._act.ctypes.data
+        self._ring_base = self.ring.base
+        self._push = self.L.pda_nstep_push
 
     def _state(self, s):
+        if type(s) is np.ndarray and s.dtype == self.state_np and s.flags.c_contiguous:
+            return s
         return np.ascontiguousarray(s, dtype=self.state_np)
 
     def reset(self, state):
@@ -143,11 +150,14 @@ class NativeFeeder(object):
 
     def push(self, action, reward, state1, terminal1, qvalue=None, max_qvalue=None):
         s = self._state(state1)
-        self._act[:] = np.asarray(action, dtype=np.float32).reshape(-1)
-        has_q = qvalue is not None and max_qvalue is not None
-        return self._check(self.L.pda_nstep_push(
-            self.h, self.ring.base, self._act.ctypes.data, float(reward), s.ctypes.data, int(bool(terminal1)),
-            float(qvalue) if has_q else 0.0, float(max_qvalue) if has_q else 0.0, int(has_q), self.timeout_ms))
+        self._act[:] = action.reshape(-1) if type(action) is np.ndarray else np.asarray(action).reshape(-1)
+        if qvalue is not None and max_qvalue is not None:
+            rc = self._push(self.h, self._ring_base, self._act_ptr, reward, s.ctypes.data, 1 if terminal1 else 0,
+                            qvalue, max_qvalue, 1, self.timeout_ms)
+        else:
+            rc = self._push(self.h, self._ring_base, self._act_ptr, reward, s.ctypes.data, 1 if terminal1 else 0,
+                            0.0, 0.0, 0, self.timeout_ms)
+        return rc if rc >= 0 else self._check(rc)
 
     def flush(self, max_qvalue_last=None):
         has = max_qvalue_last is not None

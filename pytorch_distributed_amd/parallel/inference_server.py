@@ -35,6 +35,7 @@ class InferenceMailbox(object):
         self.action_shape = int(action_shape)
         self._np = None
         self._count = {}
+        self._obs_ptr = {}
         self._ids = None
 
     def _views(self):
@@ -46,6 +47,7 @@ class InferenceMailbox(object):
         d = self.__dict__.copy()
         d["_np"] = None
         d["_count"] = {}
+        d["_obs_ptr"] = {}
         d["_ids"] = None
         return d
 
@@ -64,13 +66,17 @@ class InferenceMailbox(object):
         envs steps env B while the server answers env A.  Returns the request number."""
         L = hostlib.lib()
         obs, _, seq = self._views()
-        src = np.ascontiguousarray(state, dtype=obs.dtype).reshape(-1)
+        src = state if (type(state) is np.ndarray and state.dtype == obs.dtype and state.flags.c_contiguous) \
+            else np.ascontiguousarray(state, dtype=obs.dtype)
         k = self._count.get(slot)
         if k is None:
             k = int(L.pda_atomic_load(self._req_ptr(slot)))
         k += 1
         self._count[slot] = k
-        L.pda_mailbox_send(seq, slot, k, obs[slot].ctypes.data, src.ctypes.data, src.nbytes)
+        dst = self._obs_ptr.get(slot)
+        if dst is None:         # (per process: the address of this slot's observation in the shared mapping)
+            dst = self._obs_ptr[slot] = obs[slot].ctypes.data
+        L.pda_mailbox_send(seq, slot, k, dst, src.ctypes.data, src.nbytes)
         return k
 
     def wait(self, slot, k, timeout_s=120.0):
