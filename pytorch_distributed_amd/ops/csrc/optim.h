@@ -48,7 +48,13 @@ struct AdamExtras {
                             // backward reads as its B operand (mlp_fused.hip); pitch 0 = none
     float* tgt; bf16_t* tgt_shadow; float tau;      // target network updated in the same pass: tgt += tau (p - tgt),
                                                     // with its shadow (same segment table); tgt == nullptr = off
+    // prioritized replay: the first repair level of the sum / min tree (replay_kernels.hip) rides in this launch --
+    // the leaves of the rep_n sampled rows were written by the loss kernel earlier in the step; one wave per row
+    // recomputes that leaf's parent from its 64 children (idempotent on duplicates).  rep_sum == nullptr = off
+    float* rep_sum; float* rep_min; const int* rep_idx; int rep_n; int rep_parent_off;
 };
+__host__ __device__ inline int adam_sampler_blocks(const AdamExtras& x) { return x.next_idx ? (x.next_B + 255) / 256 : 0; }
+__host__ __device__ inline int adam_repair_blocks(const AdamExtras& x) { return x.rep_sum ? (x.rep_n + 3) / 4 : 0; }
 
 // the extra copies of a freshly updated weight (see AdamExtras): e = element within segment `seg`, ip = master index
 __device__ __forceinline__ void put_extras(const AdamExtras& x, bf16_t* shadow, const SegEntry& s, int seg, int e,
@@ -129,6 +135,20 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
                                            const int2* __restrict__ chunks, int nchunks,
                                            const float* __restrict__ hyper,
                                            const int* __restrict__ step, const AdamExtras& x, int bid, float* row) {
+    if (bid >= nchunks + adam_sampler_blocks(x)) {      // tree-repair blocks (only launched when x.rep_sum is set)
+        const int wave = (bid - nchunks - adam_sampler_blocks(x)) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (wave < x.rep_n) {
+            const int node = x.rep_idx[wave] >> 6;
+            const long child = (long)node * 64 + lane;          // level 0 starts at offset 0
+            const float s = wave_sum(x.rep_sum[child]);
+            const float q = wave_min(x.rep_min[child]);
+            if (lane == 0) {
+                x.rep_sum[x.rep_parent_off + node] = s;
+                x.rep_min[x.rep_parent_off + node] = q;
+            }
+        }
+        return;
+    }
     if (bid >= nchunks) {       // sampler blocks (only launched when x.next_idx is set)
         int i = (bid - nchunks) * 256 + threadIdx.x;
         if (i < x.next_B) {

@@ -52,17 +52,46 @@ __global__ __launch_bounds__(256) void segtree_sample_kernel(const float* __rest
                                                              const float* __restrict__ uniforms, int B, float beta,
                                                              int* __restrict__ out_idx, float* __restrict__ out_w,
                                                              unsigned long long seed,
-                                                             const unsigned long long* __restrict__ counter) {
+                                                             const unsigned long long* __restrict__ counter,
+                                                             int ntop, float* __restrict__ sum_w,
+                                                             float* __restrict__ mn_w) {
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= B) return;
     int top = offs.off[depth - 1];
-    float kid = sum[top + lane];
+    float kid, kmin;
+    if (ntop > 0 && depth >= 2) {
+        // The top level (ntop <= 64 nodes) is NOT read: every wave re-derives it from the level below -- ntop
+        // coalesced rows of 64, eight in flight at a time -- so a priority update has to repair the tree only up to
+        // that level (the engines fold the first repair level into their optimizer launch: a prioritized step then
+        // has no repair launches of its own on trees of <= 262 k leaves, one on larger ones).  Wave 0 writes the
+        // level back for host-side readers.
+        const long below = offs.off[depth - 2];
+        kid = 0.f; kmin = INFINITY;
+        for (int j0 = 0; j0 < ntop; j0 += 8) {
+            float c[8], m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = min(j0 + u, ntop - 1);
+                c[u] = sum[below + (long)j * RADIX + lane];
+                m[u] = mn[below + (long)j * RADIX + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float s = wave_sum(c[u]), q = wave_min(m[u]);
+                if (lane == j0 + u && j0 + u < ntop) { kid = s; kmin = q; }
+            }
+        }
+        if (wave == 0 && sum_w) { sum_w[top + lane] = kid; mn_w[top + lane] = kmin; }
+    } else {
+        kid = sum[top + lane];
+        kmin = mn[top + lane];
+    }
     // uniforms == nullptr: the stratum's uniform is drawn here (the same counter hash as uniform_f32_kernel: one launch
     // less per prioritized step)
     const float u = uniforms ? uniforms[wave]
                              : u01(hash_u32(seed ^ (*counter * 0x9e3779b97f4a7c15ULL + (unsigned long long)wave + 1)));
     float total = wave_sum(kid);
-    float pmin = wave_min(mn[top + lane]);
+    float pmin = wave_min(kmin);
     float v = ((float)wave + u) / (float)B * total;
     int node = 0;
     for (int lvl = depth - 1; lvl >= 0; --lvl) {
@@ -91,26 +120,29 @@ __global__ __launch_bounds__(256) void segtree_sample_kernel(const float* __rest
         out_w[wave] = __powf(ratio, beta);
     }
 }
-PDA_EXPORT void pda_segtree_sample(const void* sum, const void* mn, const int* offs, int depth, int num_leaves,
+// ntop: nodes of the top level (re-derived from the level below by every wave and written back); 0 = read it as stored
+PDA_EXPORT void pda_segtree_sample(void* sum, void* mn, const int* offs, int depth, int num_leaves,
                                    const void* uniforms, int B, float beta, void* out_idx, void* out_w,
-                                   hipStream_t stream) {
+                                   int ntop, hipStream_t stream) {
     TreeOffsets o;
     for (int i = 0; i < 8; ++i) o.off[i] = offs[i];
     long threads = (long)B * 64;
     hipLaunchKernelGGL(segtree_sample_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
                        (const float*)sum, (const float*)mn, o, depth, num_leaves, (const float*)uniforms, B, beta,
-                       (int*)out_idx, (float*)out_w, 0ull, (const unsigned long long*)nullptr);
+                       (int*)out_idx, (float*)out_w, 0ull, (const unsigned long long*)nullptr, ntop, (float*)sum,
+                       (float*)mn);
 }
 // the same draw with the uniforms generated in the kernel from (seed, *counter): see uniform_f32_kernel
-PDA_EXPORT void pda_segtree_sample_rng(const void* sum, const void* mn, const int* offs, int depth, int num_leaves,
+PDA_EXPORT void pda_segtree_sample_rng(void* sum, void* mn, const int* offs, int depth, int num_leaves,
                                        int B, float beta, void* out_idx, void* out_w, unsigned long long seed,
-                                       const void* counter, hipStream_t stream) {
+                                       const void* counter, int ntop, hipStream_t stream) {
     TreeOffsets o;
     for (int i = 0; i < 8; ++i) o.off[i] = offs[i];
     long threads = (long)B * 64;
     hipLaunchKernelGGL(segtree_sample_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
                        (const float*)sum, (const float*)mn, o, depth, num_leaves, (const float*)nullptr, B, beta,
-                       (int*)out_idx, (float*)out_w, seed, (const unsigned long long*)counter);
+                       (int*)out_idx, (float*)out_w, seed, (const unsigned long long*)counter, ntop, (float*)sum,
+                       (float*)mn);
 }
 
 // uniform index draw on device (counter-based, graph-replayable: the counter lives in memory).

@@ -259,6 +259,13 @@ class DqnCnnEngine(object):
         if self.presamples(staged):
             x.next_idx, x.next_w, x.next_B = self.idx.data_ptr(), self.isw.data_ptr(), self.B
             x.size, x.seed, x.counter = self.size_dev.data_ptr(), self.seed, self.counter.data_ptr()
+        tree = self.replay[3] if (self.replay is not None and not staged and self.per is not None) else None
+        if tree is not None and getattr(tree, "lazy_top", False):
+            # prioritized replay: the first repair level of the sum / min tree rides in the optimizer launch (the
+            # leaves were written by the head kernel), the top level is re-derived by the next step's sampling kernel:
+            # post_update() launches repairs only for the levels in between (none on trees of <= 262 k leaves)
+            x.rep_sum, x.rep_min, x.rep_idx = tree.sum.data_ptr(), tree.min.data_ptr(), self.idx.data_ptr()
+            x.rep_n, x.rep_parent_off = self.B, int(tree.offsets[1])
         return x
 
     def presamples(self, staged):
@@ -351,14 +358,19 @@ class DqnCnnEngine(object):
     def update(self, staged=False, tick=False, extras=None):
         """tick: bump Adam's step counter here (the head kernel does it in a full step)."""
         self.adam.step(tick=tick, extras=extras)
-        self.post_update(staged)
+        self.post_update(staged, repair_from=2 if (extras is not None and extras.rep_sum) else 1)
 
-    def post_update(self, staged=False):
-        """What follows the optimizer: soft target update, sum/min-tree repair of the sampled leaves."""
+    def post_update(self, staged=False, repair_from=1):
+        """What follows the optimizer: soft target update, sum/min-tree repair of the sampled leaves (repair_from = 2:
+        level 1 was repaired inside the optimizer launch and the sampling kernel re-derives the top level)."""
         if self.target_update < 1.0:
             self._target_copy(self.target_update)
         if not staged and self.per is not None and self.replay[3] is not None:
-            self.replay[3].repair(self.idx, self.B)
+            tree = self.replay[3]
+            if repair_from == 2:
+                tree.repair(self.idx, self.B, first_level=2, stop_level=tree.depth - 1)
+            else:
+                tree.repair(self.idx, self.B)
 
     def hard_target_update(self):
         self._target_copy(1.0)

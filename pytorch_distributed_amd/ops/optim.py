@@ -69,7 +69,9 @@ def plain_table(numel, device):
 class AdamExtras(ctypes.Structure):     # mirrors AdamExtras in csrc/rl_kernels.hip
     _fields_ = [("slab", _vp), ("slabinfo", _vp), ("next_idx", _vp), ("next_w", _vp), ("next_B", ctypes.c_int),
                 ("size", _vp), ("seed", ctypes.c_ulonglong), ("counter", _vp), ("shadow_plane", ctypes.c_long),
-                ("tinfo", _vp), ("tgt", _vp), ("tgt_shadow", _vp), ("tau", ctypes.c_float)]
+                ("tinfo", _vp), ("tgt", _vp), ("tgt_shadow", _vp), ("tau", ctypes.c_float),
+                ("rep_sum", _vp), ("rep_min", _vp), ("rep_idx", _vp), ("rep_n", ctypes.c_int),
+                ("rep_parent_off", ctypes.c_int)]
 
 
 class FlatAdam(object):

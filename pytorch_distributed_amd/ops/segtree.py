@@ -94,29 +94,43 @@ class DeviceSumMinTree(object):
         else:
             self.repair(leaf_inds)
 
-    def repair(self, leaf_inds, n=None):
-        """Recompute every ancestor of the given leaves (their values were already
-        written, e.g. by the fused TD kernel)."""
+    def repair(self, leaf_inds, n=None, first_level=1, stop_level=None):
+        """Recompute the ancestors of the given leaves (their values were already written, e.g. by the fused TD
+        kernel) on levels first_level .. stop_level - 1 (default: all of them, 1 .. depth - 1)."""
         n = int(leaf_inds.numel()) if n is None else n
         if not self.native:
             self._repair_cpu(leaf_inds.cpu())
             return
         L = lib()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        for lvl in range(1, self.depth):
+        for lvl in range(first_level, self.depth if stop_level is None else stop_level):
             L.pda_segtree_repair_level(_p(self.sum), _p(self.min), _p(leaf_inds), n,
                                        self.offsets[lvl - 1], self.offsets[lvl], lvl, _s(stream))
 
+    @property
+    def lazy_top(self):
+        """True when the sampling kernel re-derives the top level from the level below it (native trees of depth
+        >= 2): a priority update then only has to repair levels 1 .. depth - 2 (repair(stop_level=depth - 1)); the
+        stored top level is refreshed by the next sample and total() / min_value() read the level below."""
+        return self.native and self.depth >= 2
+
+    def _summary_level(self):
+        lvl = self.depth - 2 if self.lazy_top else self.depth - 1
+        return self.offsets[lvl], (self.sizes[lvl] if lvl < self.depth - 1 else RADIX)
+
     def total(self):
-        top = self.offsets[-1]
-        return self.sum[top:top + RADIX].sum()
+        off, n = self._summary_level()
+        return self.sum[off:off + n].sum()
 
     def min_value(self):
-        top = self.offsets[-1]
-        return self.min[top:top + RADIX].min()
+        off, n = self._summary_level()
+        return self.min[off:off + n].min()
 
     def get(self, leaf_inds):
         return self.sum[leaf_inds.long()]
+
+    def _ntop(self):
+        return int(self.sizes[-1]) if self.lazy_top else 0
 
     def sample_rng(self, B, beta, seed, counter, out_idx, out_weight):
         """sample() with the B stratum uniforms drawn inside the kernel from (seed, *counter) -- the counter hash of
@@ -127,10 +141,12 @@ class DeviceSumMinTree(object):
         offs = (ctypes.c_int * 8)(*([int(o) for o in self.offsets] + [0] * (8 - self.depth)))
         L.pda_segtree_sample_rng.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
-                                             ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p]
+                                             ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_void_p]
         L.pda_segtree_sample_rng.restype = None
         L.pda_segtree_sample_rng(_p(self.sum), _p(self.min), offs, self.depth, self.num_leaves, int(B),
-                                 ctypes.c_float(beta), _p(out_idx), _p(out_weight), int(seed), _p(counter), _s(stream))
+                                 ctypes.c_float(beta), _p(out_idx), _p(out_weight), int(seed), _p(counter),
+                                 self._ntop(), _s(stream))
         return out_idx, out_weight
 
     def sample(self, uniforms, beta, out_idx=None, out_weight=None):
@@ -146,7 +162,8 @@ class DeviceSumMinTree(object):
             stream = torch.cuda.current_stream(self.device).cuda_stream
             offs = (ctypes.c_int * 8)(*([int(o) for o in self.offsets] + [0] * (8 - self.depth)))
             L.pda_segtree_sample(_p(self.sum), _p(self.min), offs, self.depth, self.num_leaves,
-                                 _p(uniforms), B, ctypes.c_float(beta), _p(out_idx), _p(out_weight), _s(stream))
+                                 _p(uniforms), B, ctypes.c_float(beta), _p(out_idx), _p(out_weight), self._ntop(),
+                                 _s(stream))
             return out_idx, out_weight
         total = self.total().double()
         v = ((torch.arange(B, dtype=torch.float64) + uniforms.double().cpu()) / B * total).float()

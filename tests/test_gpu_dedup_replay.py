@@ -110,3 +110,40 @@ def test_synthetic_fill_and_window_draw():
     i = torch.arange(8, device="cuda", dtype=torch.int32)
     assert torch.equal(m.states(m.ref0, i)[1:, 0], m.states(m.ref0, i)[:-1, 1])
     m.close()
+
+
+@pytest.mark.parametrize("size", [4096, 50000, 300000])
+def test_prioritized_step_keeps_the_tree_consistent_without_repair_launches_of_its_own(size):
+    """The first repair level rides in the optimizer launch, the top level is re-derived by the sampling kernel
+    (ops/segtree.py lazy_top): after some updates every inner node still is the sum / min of its children."""
+    from pytorch_distributed_amd.ops.dqn_engine import DqnNativeCore
+    from pytorch_distributed_amd.ops.segtree import RADIX
+    from pytorch_distributed_amd.utils.factory import MemoriesDict, ModelsDict
+    opt = options("device-dedup-per", size, 64, "bf16")
+    memory = MemoriesDict[opt.memory_type](opt.memory_params)
+    memory.attach("cuda")
+    memory.fill_synthetic(size, nstep=5, num_actions=6)
+    torch.manual_seed(0)
+    model = ModelsDict[opt.model_type](opt.model_params, opt.norm_val, opt.state_shape, opt.action_space, 1).cuda()
+    target = ModelsDict[opt.model_type](opt.model_params, opt.norm_val, opt.state_shape, opt.action_space, 1).cuda()
+    core = DqnNativeCore(opt, model, target, memory)
+    tree = memory.tree
+    assert tree.lazy_top and tree.depth == {4096: 2, 50000: 3, 300000: 4}[size]
+    before = tree.sum[:size].clone()
+    for _ in range(12):
+        core.step()
+    core.engine.sample()            # the next step's draw refreshes the stored top level
+    torch.cuda.synchronize()
+    assert not torch.equal(before, tree.sum[:size])         # priorities were written back
+    for lvl in range(1, tree.depth):
+        avail = tree.sizes[lvl - 1] // RADIX        # nodes of this level that have (whole rows of) children
+        kids_s = tree.sum[tree.offsets[lvl - 1]:tree.offsets[lvl - 1] + avail * RADIX]
+        kids_m = tree.min[tree.offsets[lvl - 1]:tree.offsets[lvl - 1] + avail * RADIX]
+        want_s = kids_s[:avail * RADIX].view(avail, RADIX).double().sum(1)
+        want_m = kids_m[:avail * RADIX].view(avail, RADIX).min(1)[0]
+        got_s = tree.sum[tree.offsets[lvl]:tree.offsets[lvl] + avail].double()
+        got_m = tree.min[tree.offsets[lvl]:tree.offsets[lvl] + avail]
+        assert torch.allclose(got_s, want_s, rtol=1e-5, atol=1e-6), lvl
+        assert torch.equal(got_m, want_m), lvl
+    assert abs(float(tree.total()) - float(tree.sum[:size].double().sum())) < 1e-3 * float(tree.total())
+    memory.close()
