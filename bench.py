@@ -83,9 +83,11 @@ def parse_args(argv=None):
                     help="learner steps of the --node job (200 k = >= 20 s of steady learning = >= 10 logger windows of "
                          "2 s, whose mean / std / min / max are reported)")
     ap.add_argument("--node-actors", type=int, default=8)
-    ap.add_argument("--node-envs-per-actor", type=int, default=4,
-                    help="envs per actor process (pipelined requests); 2 -> 4 lifts the env side from ~460 k to ~780 k "
-                         "frames/s on 16 host cores while the learner keeps its rate (profiles/r3_node_learner_loop.txt)")
+    ap.add_argument("--node-envs-per-actor", type=int, default=16,
+                    help="envs per actor process, one inference request in flight per env: an actor process at 4 envs "
+                         "spends 63 %% of its time waiting for answers; 4 / 8 / 16 / 32 envs give 0.68 / 0.98 / 1.43 / 1.82 M "
+                         "env frames/s on 16 host cores with the learner at 9.88 / 9.74 / 9.75 / 9.63 k updates/s "
+                         "(profiles/r3_node_envs_per_actor_sweep.txt)")
     ap.add_argument("--node-memory", default="device-dedup",
                     help="replay kind of the --node job: device-dedup (every frame stored once: 1.11 planes = 7.9 KB per "
                          "transition in the job instead of 56.5 KB; 307 s soak profiles/r3_node_soak_dedup_3M_steps.json) "

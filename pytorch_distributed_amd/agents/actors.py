@@ -215,10 +215,28 @@ def _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model
             last_beat = now
 
 
+def _profiled(fn, process_ind, args):
+    """PDA_ACTOR_PROF=1: actor 1 runs under cProfile and leaves <log_dir>/actor_profile.txt (where an env step's host
+    time goes: env, n-step feeder, mailbox round trip, bookkeeping)."""
+    if process_ind != 1 or os.environ.get("PDA_ACTOR_PROF", "0") != "1":
+        return fn()
+    import cProfile
+    import io
+    import pstats
+    prof = cProfile.Profile()
+    try:
+        return prof.runcall(fn)
+    finally:
+        out = io.StringIO()
+        pstats.Stats(prof, stream=out).sort_stats("tottime").print_stats(30)
+        with open(os.path.join(args.log_dir, "actor_profile.txt"), "w") as f:
+            f.write(out.getvalue())
+
+
 def dqn_actor(process_ind, args, global_logs, actor_logs, env_prototype, model_prototype,
               global_memory, global_model):
-    _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model_prototype,
-                global_memory, global_model, "dqn")
+    _profiled(lambda: _actor_loop(process_ind, args, global_logs, actor_logs, env_prototype, model_prototype,
+                                  global_memory, global_model, "dqn"), process_ind, args)
 
 
 def ddpg_actor(process_ind, args, global_logs, actor_logs, env_prototype, model_prototype,
