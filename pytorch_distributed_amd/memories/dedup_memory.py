@@ -138,10 +138,17 @@ class DedupDeviceMemory(DeviceMemory):
         plane_base, trans_pos, first = self._place(counts)
         rows = self.trans_linear - first
         n_t = self.trans_linear - old_total
+        fused_leaves = self.tree is not None and self.tree.native
+        c = self.codec
         replay_ops.unpack_runs(records_dev, n, self.run_codec, counts, plane_base, trans_pos, self.planes, self.tails,
-                               self.ref0, self.refN, self.window_dev, (rows, first % N, N))
+                               self.ref0, self.refN, self.window_dev, (rows, first % N, N),
+                               leaves=(self.tree.sum, self.tree.min, c.action_shape + 3 * c.num_tasks, self.priority_eps,
+                                       self.priority_exponent) if fused_leaves else None)
         if self.tree is not None:
-            if n_t:
+            if n_t and fused_leaves:
+                # the unpack kernel wrote the new rows' leaves; one single-workgroup launch repairs above them
+                self.tree.repair_range(old_total % N, n_t)
+            elif n_t:
                 pos = ((torch.arange(n_t, device=self.device) + old_total) % N).to(torch.int32)
                 self.tree.update(pos, self._leaf_priority(self.init_priorities[pos.long()]))
             # rows that left the window without being overwritten by this chunk keep no mass

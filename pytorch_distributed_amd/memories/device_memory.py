@@ -165,6 +165,14 @@ class DeviceMemory(Memory):
             # uniform replay: the kernel derives every record's ring slot from (pos, m) itself -- no index tensor
             replay_ops.unpack_records(records_dev, n, None, self.state0s, self.state1s, self.tails,
                                       c.state_bytes, c.state_stride, c.tail_floats, pos_start=self.pos)
+        elif self.tree.native:
+            # prioritized, on the GPU: the unpack kernel also writes the new rows' leaves (|p| + eps)^alpha, one
+            # single-workgroup launch repairs the tree above them (~12 launches per chunk before)
+            replay_ops.unpack_records(records_dev, n, None, self.state0s, self.state1s, self.tails,
+                                      c.state_bytes, c.state_stride, c.tail_floats, pos_start=self.pos,
+                                      leaves=(self.tree.sum, self.tree.min, c.action_shape + 3 * c.num_tasks,
+                                              self.priority_eps, self.priority_exponent))
+            self.tree.repair_range(self.pos, n)
         else:
             base = self._pos_base[:n] if n <= self._pos_base.numel() else torch.arange(n, device=self.device)
             positions = ((base + self.pos) % m).to(torch.int32)

@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256) void replay_unpack_kernel(const uint8_t* __res
                                                             const int* __restrict__ pos, long pos_start, long ring_size,
                                                             uint8_t* __restrict__ s0, uint8_t* __restrict__ s1,
                                                             int state_bytes, int state_stride,
-                                                            float* __restrict__ tails, int tail_ld, int tail_floats) {
+                                                            float* __restrict__ tails, int tail_ld, int tail_floats,
+                                                            float* __restrict__ leaf_sum, float* __restrict__ leaf_min,
+                                                            int prio_at, float prio_eps, float prio_alpha) {
     int r = blockIdx.x;
     const uint8_t* src = rec + (long)r * rec_stride;
     const long slot = pos ? (long)pos[r] : (pos_start + r) % ring_size;
@@ -203,13 +205,20 @@ __global__ __launch_bounds__(256) void replay_unpack_kernel(const uint8_t* __res
     }
     const float* tl = reinterpret_cast<const float*>(src + 2 * (long)state_stride);
     if (threadIdx.x < tail_floats) tails[slot * tail_ld + threadIdx.x] = tl[threadIdx.x];
+    if (threadIdx.x == 128 && leaf_sum) {           // prioritized replay: the row's leaf (|p| + eps)^alpha in both trees
+        const float v = powf(fabsf(tl[prio_at]) + prio_eps, prio_alpha);
+        leaf_sum[slot] = v;
+        leaf_min[slot] = v;
+    }
 }
 PDA_EXPORT void pda_replay_unpack(const void* rec, long rec_stride, int n, const void* pos, long pos_start,
                                   long ring_size, void* s0, void* s1, int state_bytes, int state_stride, void* tails,
-                                  int tail_ld, int tail_floats, hipStream_t stream) {
+                                  int tail_ld, int tail_floats, void* leaf_sum, void* leaf_min, int prio_at,
+                                  float prio_eps, float prio_alpha, hipStream_t stream) {
     hipLaunchKernelGGL(replay_unpack_kernel, dim3(n), dim3(256), 0, stream, (const uint8_t*)rec, rec_stride,
                        (const int*)pos, pos_start, ring_size > 0 ? ring_size : 1, (uint8_t*)s0, (uint8_t*)s1,
-                       state_bytes, state_stride, (float*)tails, tail_ld, tail_floats);
+                       state_bytes, state_stride, (float*)tails, tail_ld, tail_floats, (float*)leaf_sum,
+                       (float*)leaf_min, prio_at, prio_eps, prio_alpha);
 }
 
 // ---- replay: gather B rows of row_bytes (multiple of 16) ------------------------------------------
@@ -242,7 +251,9 @@ __global__ __launch_bounds__(256) void replay_unpack_runs_kernel(const uint8_t* 
                                                                  float* __restrict__ tails, int tail_ld,
                                                                  int* __restrict__ ref0, int* __restrict__ refN,
                                                                  int* __restrict__ window, int w_rows, int w_first,
-                                                                 int w_ring) {
+                                                                 int w_ring, float* __restrict__ leaf_sum,
+                                                                 float* __restrict__ leaf_min, int prio_at,
+                                                                 float prio_eps, float prio_alpha) {
     const int j = blockIdx.x, r = blockIdx.y;
     const uint8_t* src = rec + (long)r * rec_stride;
     const PdaRunHeader* h = reinterpret_cast<const PdaRunHeader*>(src);
@@ -264,8 +275,13 @@ __global__ __launch_bounds__(256) void replay_unpack_runs_kernel(const uint8_t* 
             ref0[slot] = base + offs[0];
             refN[slot] = base + offs[1];
         }
+        if (threadIdx.x == 128 && leaf_sum) {       // prioritized replay: the row's leaf (|p| + eps)^alpha in both trees
+            const float v = powf(fabsf(tl[prio_at]) + prio_eps, prio_alpha);
+            leaf_sum[slot] = v;
+            leaf_min[slot] = v;
+        }
     }
-    if (j == 0 && r == 0 && threadIdx.x == 128 && window) {
+    if (j == 0 && r == 0 && threadIdx.x == 192 && window) {
         window[0] = w_rows; window[1] = w_first; window[2] = w_ring;
     }
 }
@@ -273,6 +289,7 @@ PDA_EXPORT int pda_replay_unpack_runs(const void* rec, long rec_stride, int n_ru
                                       const int* trans_pos, int trans_ring, void* planes, int plane_stride,
                                       int plane_cap, int trans_cap, int tail_floats, void* tails, int tail_ld,
                                       void* ref0, void* refN, void* window, int w_rows, int w_first, int w_ring,
+                                      void* leaf_sum, void* leaf_min, int prio_at, float prio_eps, float prio_alpha,
                                       hipStream_t stream) {
     if (n_runs < 1 || n_runs > PDA_MAX_RUNS || plane_stride % 16 != 0 || tail_floats > 64) return -1;
     RunPlacement pl;
@@ -285,6 +302,45 @@ PDA_EXPORT int pda_replay_unpack_runs(const void* rec, long rec_stride, int n_ru
                        rec_stride, pl, trans_ring, (uint8_t*)planes, plane_stride,
                        (int)pda_run_planes_offset((uint32_t)tail_floats, (uint32_t)trans_cap),
                        (int)pda_run_trans_stride((uint32_t)tail_floats), tail_floats, (float*)tails, tail_ld, (int*)ref0,
-                       (int*)refN, (int*)window, w_rows, w_first, w_ring);
+                       (int*)refN, (int*)window, w_rows, w_first, w_ring, (float*)leaf_sum, (float*)leaf_min, prio_at,
+                       prio_eps, prio_alpha);
     return 0;
+}
+
+// ---- tree repair for a contiguous (mod ring) run of `count` leaves starting at `start`: levels 1 .. stop - 1 in ONE
+// launch of one workgroup (16 waves; a wave per node, levels separated by workgroup barriers).  What replay ingestion
+// needs after it has written the leaves of a chunk of new rows: a few hundred consecutive leaves touch ~10 nodes of
+// level 1 and one or two of every level above, so there is nothing to spread over the GPU -- and nothing to launch
+// level by level (set_leaves + 3 repair launches + the index arithmetic around them: ~12 launches per chunk before).
+__global__ __launch_bounds__(1024) void segtree_repair_range_kernel(float* __restrict__ sum, float* __restrict__ mn,
+                                                                    TreeOffsets offs, int stop, int start, int count,
+                                                                    int ring) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the run as up to two plain ranges [a0, b0) and [0, b1)
+    const int a0 = start, b0 = min(start + count, ring), b1 = start + count > ring ? start + count - ring : 0;
+    for (int lvl = 1; lvl < stop; ++lvl) {
+        const int sh = 6 * lvl;
+        const int n0lo = a0 >> sh, n0hi = (b0 - 1) >> sh;                   // nodes of this level above [a0, b0)
+        const int c0 = b0 > a0 ? n0hi - n0lo + 1 : 0;
+        const int c1 = b1 > 0 ? ((b1 - 1) >> sh) + 1 : 0;                   // ... and above [0, b1)
+        for (int i = wave; i < c0 + c1; i += 16) {
+            const int node = i < c0 ? n0lo + i : i - c0;
+            const long child = (long)offs.off[lvl - 1] + (long)node * RADIX + lane;
+            const float s = wave_sum(sum[child]);
+            const float q = wave_min(mn[child]);
+            if (lane == 0) {
+                sum[offs.off[lvl] + node] = s;
+                mn[offs.off[lvl] + node] = q;
+            }
+        }
+        __syncthreads();        // (plain global stores of this workgroup are visible to it after the barrier)
+    }
+}
+PDA_EXPORT void pda_segtree_repair_range(void* sum, void* mn, const int* offs, int stop, int start, int count,
+                                         int ring, hipStream_t stream) {
+    if (count <= 0 || stop <= 1) return;
+    TreeOffsets o;
+    for (int i = 0; i < 8; ++i) o.off[i] = offs[i];
+    hipLaunchKernelGGL(segtree_repair_range_kernel, dim3(1), dim3(1024), 0, stream, (float*)sum, (float*)mn, o, stop,
+                       start, count, ring);
 }

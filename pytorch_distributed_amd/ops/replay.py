@@ -21,10 +21,11 @@ def _stream(device):
 
 
 def unpack_records(records, n, positions, state0s, state1s, tails, state_bytes, state_stride, tail_floats,
-                   pos_start=0):
+                   pos_start=0, leaves=None):
     """records (>=n, record_bytes) uint8 on the replay device; positions (n,)
     int32 ring slots, or None: record r goes to slot (pos_start + r) mod len(state0s), computed
-    inside the kernel.  Writes state0s[pos], state1s[pos] (raw bytes) and tails[pos, :tail_floats]."""
+    inside the kernel.  Writes state0s[pos], state1s[pos] (raw bytes) and tails[pos, :tail_floats].
+    leaves: as unpack_runs (GPU only)."""
     if n == 0:
         return
     dev = state0s.device
@@ -37,7 +38,12 @@ def unpack_records(records, n, positions, state0s, state1s, tails, state_bytes, 
                                 _p(positions) if positions is not None else ctypes.c_void_p(0),
                                 ctypes.c_long(int(pos_start)), ctypes.c_long(m),
                                 _p(state0s), _p(state1s), int(state_bytes), int(state_stride),
-                                _p(tails), int(tails.stride(0)), int(tail_floats), _stream(dev))
+                                _p(tails), int(tails.stride(0)), int(tail_floats),
+                                _p(leaves[0]) if leaves else ctypes.c_void_p(0),
+                                _p(leaves[1]) if leaves else ctypes.c_void_p(0),
+                                ctypes.c_int(int(leaves[2]) if leaves else 0),
+                                ctypes.c_float(float(leaves[3]) if leaves else 0.0),
+                                ctypes.c_float(float(leaves[4]) if leaves else 1.0), _stream(dev))
         return
     if positions is None:
         positions = (torch.arange(n, device=dev) + int(pos_start)) % m
@@ -51,11 +57,15 @@ def unpack_records(records, n, positions, state0s, state1s, tails, state_bytes, 
     tails[pos, :tail_floats] = tail
 
 
-def unpack_runs(records, n_runs, codec, counts, plane_base, trans_pos, planes, tails, ref0, refN, window, window_vals):
+def unpack_runs(records, n_runs, codec, counts, plane_base, trans_pos, planes, tails, ref0, refN, window, window_vals,
+                leaves=None):
     """Frame-deduplicated replay (parallel/csrc/frame_runs.h): copy the planes of n_runs run records to
     planes[plane_base[r] ...] and their transitions to ring rows trans_pos[r] ... (mod len(tails)): tails, and the two
     frame windows as plane indices ref0 / refN.  counts: [(num_planes, num_transitions)] per run, read by the host
-    from the records' headers; window (int32[4], may be None) receives window_vals = (rows, first row, ring length)."""
+    from the records' headers; window (int32[4], may be None) receives window_vals = (rows, first row, ring length).
+    leaves = (tree sum, tree min, index of the priority in a tail, eps, alpha): (GPU only) the kernel also writes every
+    new row's leaf (|priority| + eps)^alpha into both trees; the caller repairs the levels above
+    (DeviceSumMinTree.repair_range)."""
     if n_runs == 0:
         return
     dev = planes.device
@@ -68,7 +78,7 @@ def unpack_runs(records, n_runs, codec, counts, plane_base, trans_pos, planes, t
         if not getattr(L, "_unpack_runs_ready", False):
             i32, vp, lng = ctypes.c_int, ctypes.c_void_p, ctypes.c_long
             L.pda_replay_unpack_runs.argtypes = [vp, lng, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp,
-                                                 i32, i32, i32, vp]
+                                                 i32, i32, i32, vp, vp, i32, ctypes.c_float, ctypes.c_float, vp]
             L.pda_replay_unpack_runs.restype = i32
             L._unpack_runs_ready = True
         pb = (ctypes.c_int * n_runs)(*[int(v) for v in plane_base])
@@ -77,7 +87,11 @@ def unpack_runs(records, n_runs, codec, counts, plane_base, trans_pos, planes, t
                                       int(planes.stride(0)), codec.plane_cap, codec.trans_cap, codec.tail_floats,
                                       _p(tails), int(tails.stride(0)), _p(ref0), _p(refN),
                                       _p(window) if window is not None else ctypes.c_void_p(0),
-                                      int(window_vals[0]), int(window_vals[1]), int(window_vals[2]), _stream(dev))
+                                      int(window_vals[0]), int(window_vals[1]), int(window_vals[2]),
+                                      _p(leaves[0]) if leaves else ctypes.c_void_p(0),
+                                      _p(leaves[1]) if leaves else ctypes.c_void_p(0),
+                                      int(leaves[2]) if leaves else 0, float(leaves[3]) if leaves else 0.0,
+                                      float(leaves[4]) if leaves else 1.0, _stream(dev))
         if rc != 0:
             raise ValueError("pda_replay_unpack_runs refused its arguments (%d runs, plane stride %d)"
                              % (n_runs, planes.stride(0)))

@@ -107,6 +107,26 @@ class DeviceSumMinTree(object):
             L.pda_segtree_repair_level(_p(self.sum), _p(self.min), _p(leaf_inds), n,
                                        self.offsets[lvl - 1], self.offsets[lvl], lvl, _s(stream))
 
+    def repair_range(self, start, count):
+        """Repair above `count` consecutive leaves (mod num_leaves) from `start` whose values were just written:
+        native trees in one single-workgroup launch, up to the level the sampling kernel re-derives (lazy_top)."""
+        count = int(min(count, self.num_leaves))
+        if count <= 0:
+            return
+        if not self.native:
+            self._repair_cpu((torch.arange(count) + int(start)) % self.num_leaves)
+            return
+        L = lib()
+        if not getattr(L, "_repair_range_ready", False):
+            L.pda_segtree_repair_range.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int),
+                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+            L.pda_segtree_repair_range.restype = None
+            L._repair_range_ready = True
+        offs = (ctypes.c_int * 8)(*([int(o) for o in self.offsets] + [0] * (8 - self.depth)))
+        stop = self.depth - 1 if self.lazy_top else self.depth
+        L.pda_segtree_repair_range(_p(self.sum), _p(self.min), offs, stop, int(start) % self.num_leaves, count,
+                                   self.num_leaves, _s(torch.cuda.current_stream(self.device).cuda_stream))
+
     @property
     def lazy_top(self):
         """True when the sampling kernel re-derives the top level from the level below it (native trees of depth
