@@ -32,7 +32,7 @@ CONFIGS = [
     ["dqn",  "synthetic", "pong",      "device-per", "dqn-cnn"],   # 5 large-batch (4096) prioritized DQN
     ["dqn",  "chain",     "chain",     "shared",     "dqn-mlp"],   # 6 tiny learnable task for sanity tests
     ["ddpg", "pendulum",  "pendulum",  "device",     "ddpg-mlp"],  # 7 DDPG with HBM replay + native kernels
-    ["dqn",  "synthetic", "minipong",  "device",     "dqn-cnn"],   # 8 row 2 on the built-in pixel Pong (envs/minipong.py)
+    ["dqn",  "synthetic", "minipong",  "device-dedup", "dqn-cnn"], # 8 row 2 on the built-in pixel Pong (envs/minipong.py)
     ["dqn",  "synthetic", "pong",      "device-dedup-per", "dqn-cnn"],   # 9 row 4 on frame-deduplicated replay (memories/dedup_memory.py)
 ]
 
@@ -76,14 +76,17 @@ PRESETS = {
     # Not needed (measured): reward scaling, separate actor/critic rates, a larger tau, critic-only warm-up (hurts).
     # 8 = the reference's README Pong setting (8 actors, n-step 5, every hyper-parameter as shipped) on MiniPong
     # (/root/reference/utils/options.py:112-141), with two additions that the reference's own speed made unnecessary:
-    #   num_envs_per_actor 4           the learner here is ~27x faster than the reference's; the 8 actor processes
-    #                                  keep up by stepping 4 envs each behind one batched inference request per env
+    #   num_envs_per_actor 16          the learner here is ~27x faster than the reference's; the 8 actor processes
+    #                                  keep up by stepping 16 envs each behind one batched inference request per env
+    #                                  (an actor process with 4 envs spends 63 % of its time waiting for answers);
+    #                                  the replay is the frame-deduplicated one (a seventh of the ingest bytes).
+    #                                  +18 after 12.3 / 12.4 / 12.7 s on 3 of 3 seeds (4 envs, full stacks: 9-46 s)
     #   max_replay_ratio 1/16          one update per 16 env steps = 8 samples per transition at batch 128, the replay
     #                                  intensity of the classic DQN recipe (batch 32 every 4 steps) and about the
     #                                  reference's own emergent ratio.  Uncoupled, the native learner runs 0.3 updates
     #                                  per env step and the evaluation score peaks at +14 and wanders between -8 and +14
     #                                  (profiles/r3_minipong_wallclock.txt); coupled it reaches +20 in ~10 s.
-    8: {"num_actors": 8, "agent_params.nstep": 5, "actor_inference": "batched", "num_envs_per_actor": 4,
+    8: {"num_actors": 8, "agent_params.nstep": 5, "actor_inference": "batched", "num_envs_per_actor": 16,
         "agent_params.max_replay_ratio": 0.0625},
     7: {"num_actors": 8, "agent_params.nstep": 1, "agent_params.lr": 1e-3,
         "agent_params.compat_ddpg_grad_leak": False, "agent_params.max_replay_ratio": 1.0,

@@ -41,10 +41,12 @@ def test_native_cores_learn_minipong_within_a_minute(core):
     assert res["learner_updates_per_sec"] > 3000 and res["env_steps_per_sec"] > 30000, res
 
 
-def test_learns_minipong_from_frame_deduplicated_replay():
-    """The same job with every frame stored once (memories/dedup_memory.py): the actors' runs, the plane ring and the
-    kernels' frame windows feed a learner that learns (measured: +18 after 12.3 / 21.4 s on two seeds)."""
-    res, text = _run("fp32", seed=2, goal=12.0, max_steps=450000, timeout=170, extra=["--set", "memory_type=device-dedup"])
+def test_learns_minipong_from_full_frame_stacks_too():
+    """Config 8 uses the frame-deduplicated replay (memories/dedup_memory.py: the actors' runs, the plane ring and the
+    kernels' frame windows feed the learner in the tests above); the same job on the plain HBM replay, which stores both
+    frame stacks of every transition, with the 4 envs per actor process the first measurements used."""
+    res, text = _run("fp32", seed=2, goal=12.0, max_steps=450000, timeout=170,
+                     extra=["--set", "memory_type=device", "--envs-per-actor", "4"])
     assert res["reached"], text[-3000:]
     assert res["eval_at_goal"] >= 12.0 and res["wall_s_from_job_start"] < 60.0, res
 
