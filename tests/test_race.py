@@ -1,5 +1,5 @@
 """Race detection for the native host runtime: the lock-free ring, the ingestion
-pump and the mailbox protocol are exercised by a multi-threaded C++ driver built with
+pump, the mailbox protocol and the frame-deduplicated run packer are exercised by a multi-threaded C++ driver built with
 ThreadSanitizer (host code only; GPU sanitizers are not available on this pool)."""
 import os
 import shutil
@@ -34,3 +34,4 @@ def test_host_runtime_under_sanitizer(tmp_path, sanitizer):
     assert res.returncode == 0, out[-3000:]
     assert "WARNING: ThreadSanitizer" not in out and "ERROR: AddressSanitizer" not in out, out[-3000:]
     assert "ring_stress ok" in out
+    assert "runs ok" in out         # the frame-deduplicated run packer (4 streams -> one ring -> checking consumer)
