@@ -52,6 +52,10 @@ struct AdamExtras {
     // the leaves of the rep_n sampled rows were written by the loss kernel earlier in the step; one wave per row
     // recomputes that leaf's parent from its 64 children (idempotent on duplicates).  rep_sum == nullptr = off
     float* rep_sum; float* rep_min; const int* rep_idx; int rep_n; int rep_parent_off;
+    // trees of three levels: the last repair block to finish also recomputes the rep_top_n nodes of the top level
+    // (at rep_top_off) from the repaired level, so such a tree is complete when this launch ends.  rep_count: a
+    // device int, zero between launches.  rep_top_n == 0 = off
+    int* rep_count; int rep_top_off; int rep_top_n;
 };
 __host__ __device__ inline int adam_sampler_blocks(const AdamExtras& x) { return x.next_idx ? (x.next_B + 255) / 256 : 0; }
 __host__ __device__ inline int adam_repair_blocks(const AdamExtras& x) { return x.rep_sum ? (x.rep_n + 3) / 4 : 0; }
@@ -145,6 +149,30 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
             if (lane == 0) {
                 x.rep_sum[x.rep_parent_off + node] = s;
                 x.rep_min[x.rep_parent_off + node] = q;
+            }
+        }
+        if (x.rep_top_n > 0) {
+            int* last = reinterpret_cast<int*>(row);
+            __syncthreads();                                    // this block's nodes are stored
+            if (threadIdx.x == 0) {
+                __threadfence();
+                const int prev = atomicAdd(x.rep_count, 1);
+                *last = prev + 1 == adam_repair_blocks(x) ? 1 : 0;
+                if (*last) *x.rep_count = 0;                    // ready for the next launch (graph replays)
+            }
+            __syncthreads();
+            if (*last) {                                        // every repair block has published its nodes
+                __threadfence();
+                for (int j = threadIdx.x >> 6; j < x.rep_top_n; j += 4) {
+                    const long child = (long)x.rep_parent_off + (long)j * 64 + lane;
+                    // device-scope loads: other blocks wrote these values during this launch
+                    const float s = wave_sum(__hip_atomic_load(x.rep_sum + child, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    const float q = wave_min(__hip_atomic_load(x.rep_min + child, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (lane == 0) {
+                        x.rep_sum[x.rep_top_off + j] = s;
+                        x.rep_min[x.rep_top_off + j] = q;
+                    }
+                }
             }
         }
         return;

@@ -260,12 +260,17 @@ class DqnCnnEngine(object):
             x.next_idx, x.next_w, x.next_B = self.idx.data_ptr(), self.isw.data_ptr(), self.B
             x.size, x.seed, x.counter = self.size_dev.data_ptr(), self.seed, self.counter.data_ptr()
         tree = self.replay[3] if (self.replay is not None and not staged and self.per is not None) else None
-        if tree is not None and getattr(tree, "lazy_top", False):
+        if tree is not None and getattr(tree, "native", False) and tree.depth >= 2:
             # prioritized replay: the first repair level of the sum / min tree rides in the optimizer launch (the
-            # leaves were written by the head kernel), the top level is re-derived by the next step's sampling kernel:
-            # post_update() launches repairs only for the levels in between (none on trees of <= 262 k leaves)
+            # leaves were written by the head kernel).  Trees of up to three levels (<= 262 k leaves) are complete when
+            # that launch ends (the last repair block recomputes the top level); larger ones get the levels in between
+            # from post_update() and their top level re-derived by the next step's sampling kernel (tree.lazy_top)
             x.rep_sum, x.rep_min, x.rep_idx = tree.sum.data_ptr(), tree.min.data_ptr(), self.idx.data_ptr()
             x.rep_n, x.rep_parent_off = self.B, int(tree.offsets[1])
+            if tree.depth == 3:
+                if getattr(self, "_rep_count", None) is None:
+                    self._rep_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+                x.rep_count, x.rep_top_off, x.rep_top_n = self._rep_count.data_ptr(), int(tree.offsets[2]), int(tree.sizes[2])
         return x
 
     def presamples(self, staged):

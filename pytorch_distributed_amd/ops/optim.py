@@ -71,7 +71,8 @@ class AdamExtras(ctypes.Structure):     # mirrors AdamExtras in csrc/rl_kernels.
                 ("size", _vp), ("seed", ctypes.c_ulonglong), ("counter", _vp), ("shadow_plane", ctypes.c_long),
                 ("tinfo", _vp), ("tgt", _vp), ("tgt_shadow", _vp), ("tau", ctypes.c_float),
                 ("rep_sum", _vp), ("rep_min", _vp), ("rep_idx", _vp), ("rep_n", ctypes.c_int),
-                ("rep_parent_off", ctypes.c_int)]
+                ("rep_parent_off", ctypes.c_int), ("rep_count", _vp), ("rep_top_off", ctypes.c_int),
+                ("rep_top_n", ctypes.c_int)]
 
 
 class FlatAdam(object):

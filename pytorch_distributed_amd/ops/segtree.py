@@ -129,10 +129,12 @@ class DeviceSumMinTree(object):
 
     @property
     def lazy_top(self):
-        """True when the sampling kernel re-derives the top level from the level below it (native trees of depth
-        >= 2): a priority update then only has to repair levels 1 .. depth - 2 (repair(stop_level=depth - 1)); the
-        stored top level is refreshed by the next sample and total() / min_value() read the level below."""
-        return self.native and self.depth >= 2
+        """True when the sampling kernel re-derives the top level from the level below it (native trees of four or
+        more levels, > 262 k leaves): a priority update then only has to repair levels 1 .. depth - 2
+        (repair(stop_level=depth - 1)); the stored top level is refreshed by the next sample and total() / min_value()
+        read the level below.  (Smaller trees are completed inside the learner's optimizer launch -- csrc/optim.h
+        AdamExtras::rep_top_n -- or by repair_range, and sampled from their stored top level.)"""
+        return self.native and self.depth >= 4
 
     def _summary_level(self):
         lvl = self.depth - 2 if self.lazy_top else self.depth - 1
