@@ -3,6 +3,7 @@
 // workgroups with the conv weight-gradient GEMMs).
 #pragma once
 #include "common.h"
+#include "segtree_dev.h"
 
 // ----------------------------------------------------------------------------
 // flat-buffer optimizer.  One launch updates every parameter, clips the gradient
@@ -56,9 +57,17 @@ struct AdamExtras {
     // (at rep_top_off) from the repaired level, so such a tree is complete when this launch ends.  rep_count: a
     // device int, zero between launches.  rep_top_n == 0 = off
     int* rep_count; int rep_top_off; int rep_top_n;
+    // ... and the NEXT step's prioritized draw rides behind it (trees of up to three levels, complete once the last
+    // repair block has finished): ps_B sampler waves, four per block, wait for that block's flag *ps_done (bounded
+    // spin), then descend the tree rep_sum / rep_min exactly as segtree_sample_kernel does (uniforms from seed and
+    // *counter).  They overwrite rep_idx's buffer -- every repair block has read it by then.  The last sampler block
+    // to finish clears the flag for the next launch.  ps_idx == nullptr = off
+    int* ps_idx; float* ps_w; int ps_B; int ps_depth; int ps_leaves; float ps_beta; TreeOffsets ps_offs;
+    int* ps_done; int* ps_count;
 };
 __host__ __device__ inline int adam_sampler_blocks(const AdamExtras& x) { return x.next_idx ? (x.next_B + 255) / 256 : 0; }
 __host__ __device__ inline int adam_repair_blocks(const AdamExtras& x) { return x.rep_sum ? (x.rep_n + 3) / 4 : 0; }
+__host__ __device__ inline int adam_per_sampler_blocks(const AdamExtras& x) { return x.ps_idx ? (x.ps_B + 3) / 4 : 0; }
 
 // the extra copies of a freshly updated weight (see AdamExtras): e = element within segment `seg`, ip = master index
 __device__ __forceinline__ void put_extras(const AdamExtras& x, bf16_t* shadow, const SegEntry& s, int seg, int e,
@@ -139,6 +148,35 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
                                            const int2* __restrict__ chunks, int nchunks,
                                            const float* __restrict__ hyper,
                                            const int* __restrict__ step, const AdamExtras& x, int bid, float* row) {
+    // Tree work of a prioritized step.  Blocks of this launch hand values to each other, so everything they exchange goes
+    // through agent-scope atomics (performed at the coherence point) and NO fence is used: an agent-scope fence writes the
+    // L2 back, which at this moment is full of the optimizer's own dirty lines (measured: the launch grew by the whole
+    // sampling kernel it was meant to absorb).  A store that must be complete before a counter / flag update is an
+    // atomic exchange whose returned value the thread waits for.
+    if (bid >= nchunks + adam_sampler_blocks(x) + adam_repair_blocks(x)) {      // prioritized sampler blocks
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(x.ps_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1u << 22))
+                __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+        const int wave = (bid - nchunks - adam_sampler_blocks(x) - adam_repair_blocks(x)) * 4 + (threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63;
+        if (wave < x.ps_B) {
+            const float u = u01(hash_u32(x.seed ^ (*x.counter * 0x9e3779b97f4a7c15ULL + (unsigned long long)wave + 1)));
+            segtree_sample_wave<true>(x.rep_sum, x.rep_min, x.ps_offs, x.ps_depth, x.ps_leaves, u, wave, lane, x.ps_B,
+                                      x.ps_beta, x.ps_idx, x.ps_w, 0, nullptr, nullptr);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int prev = atomicAdd(x.ps_count, 1);
+            if (prev + 1 == adam_per_sampler_blocks(x)) {       // the last sampler block: ready for the next launch
+                __hip_atomic_store(x.ps_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(x.ps_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
     if (bid >= nchunks + adam_sampler_blocks(x)) {      // tree-repair blocks (only launched when x.rep_sum is set)
         const int wave = (bid - nchunks - adam_sampler_blocks(x)) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (wave < x.rep_n) {
@@ -147,31 +185,39 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
             const float s = wave_sum(x.rep_sum[child]);
             const float q = wave_min(x.rep_min[child]);
             if (lane == 0) {
-                x.rep_sum[x.rep_parent_off + node] = s;
-                x.rep_min[x.rep_parent_off + node] = q;
+                if (x.rep_count) {
+                    const float r0 = atomicExch(x.rep_sum + x.rep_parent_off + node, s);
+                    const float r1 = atomicExch(x.rep_min + x.rep_parent_off + node, q);
+                    asm volatile("" :: "v"(r0), "v"(r1));       // both exchanges have returned: the nodes are in place
+                } else {
+                    x.rep_sum[x.rep_parent_off + node] = s;
+                    x.rep_min[x.rep_parent_off + node] = q;
+                }
             }
         }
-        if (x.rep_top_n > 0) {
+        if (x.rep_count) {
             int* last = reinterpret_cast<int*>(row);
             __syncthreads();                                    // this block's nodes are stored
             if (threadIdx.x == 0) {
-                __threadfence();
                 const int prev = atomicAdd(x.rep_count, 1);
                 *last = prev + 1 == adam_repair_blocks(x) ? 1 : 0;
-                if (*last) *x.rep_count = 0;                    // ready for the next launch (graph replays)
+                if (*last) __hip_atomic_store(x.rep_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
             if (*last) {                                        // every repair block has published its nodes
-                __threadfence();
                 for (int j = threadIdx.x >> 6; j < x.rep_top_n; j += 4) {
                     const long child = (long)x.rep_parent_off + (long)j * 64 + lane;
-                    // device-scope loads: other blocks wrote these values during this launch
                     const float s = wave_sum(__hip_atomic_load(x.rep_sum + child, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                     const float q = wave_min(__hip_atomic_load(x.rep_min + child, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                     if (lane == 0) {
-                        x.rep_sum[x.rep_top_off + j] = s;
-                        x.rep_min[x.rep_top_off + j] = q;
+                        const float r0 = atomicExch(x.rep_sum + x.rep_top_off + j, s);
+                        const float r1 = atomicExch(x.rep_min + x.rep_top_off + j, q);
+                        asm volatile("" :: "v"(r0), "v"(r1));
                     }
+                }
+                if (x.ps_done) {                                // the tree is complete: release the sampler blocks
+                    __syncthreads();
+                    if (threadIdx.x == 0) __hip_atomic_store(x.ps_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }

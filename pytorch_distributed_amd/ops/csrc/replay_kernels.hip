@@ -1,9 +1,8 @@
 // Prioritized-replay segment tree (radix 64 = one child per wavefront lane) and
 // HBM replay data movement.
 #include "common.h"
+#include "segtree_dev.h"
 #include "../../parallel/csrc/frame_runs.h"
-
-#define RADIX 64
 
 // ---- leaves: tree[idx[i]] = value[i] for both trees ---------------------------------
 __global__ void segtree_set_leaves_kernel(float* sum, float* mn, const int* idx, const float* val, int n) {
@@ -43,9 +42,7 @@ PDA_EXPORT void pda_segtree_repair_level(void* sum, void* mn, const void* idx, i
                        (float*)sum, (float*)mn, (const int*)idx, n, child_off, parent_off, 6 * lvl);
 }
 
-// ---- stratified prefix-sum sampling: one wave per sample ---------------------------------
-struct TreeOffsets { int off[8]; };
-
+// ---- stratified prefix-sum sampling: one wave per sample (segtree_dev.h) ---------------------------------
 __global__ __launch_bounds__(256) void segtree_sample_kernel(const float* __restrict__ sum,
                                                              const float* __restrict__ mn, TreeOffsets offs,
                                                              int depth, int num_leaves,
@@ -57,68 +54,11 @@ __global__ __launch_bounds__(256) void segtree_sample_kernel(const float* __rest
                                                              float* __restrict__ mn_w) {
     int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= B) return;
-    int top = offs.off[depth - 1];
-    float kid, kmin;
-    if (ntop > 0 && depth >= 2) {
-        // The top level (ntop <= 64 nodes) is NOT read: every wave re-derives it from the level below -- ntop
-        // coalesced rows of 64, eight in flight at a time -- so a priority update has to repair the tree only up to
-        // that level (the engines fold the first repair level into their optimizer launch: a prioritized step then
-        // has no repair launches of its own on trees of <= 262 k leaves, one on larger ones).  Wave 0 writes the
-        // level back for host-side readers.
-        const long below = offs.off[depth - 2];
-        kid = 0.f; kmin = INFINITY;
-        for (int j0 = 0; j0 < ntop; j0 += 8) {
-            float c[8], m[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = min(j0 + u, ntop - 1);
-                c[u] = sum[below + (long)j * RADIX + lane];
-                m[u] = mn[below + (long)j * RADIX + lane];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float s = wave_sum(c[u]), q = wave_min(m[u]);
-                if (lane == j0 + u && j0 + u < ntop) { kid = s; kmin = q; }
-            }
-        }
-        if (wave == 0 && sum_w) { sum_w[top + lane] = kid; mn_w[top + lane] = kmin; }
-    } else {
-        kid = sum[top + lane];
-        kmin = mn[top + lane];
-    }
     // uniforms == nullptr: the stratum's uniform is drawn here (the same counter hash as uniform_f32_kernel: one launch
     // less per prioritized step)
     const float u = uniforms ? uniforms[wave]
                              : u01(hash_u32(seed ^ (*counter * 0x9e3779b97f4a7c15ULL + (unsigned long long)wave + 1)));
-    float total = wave_sum(kid);
-    float pmin = wave_min(kmin);
-    float v = ((float)wave + u) / (float)B * total;
-    int node = 0;
-    for (int lvl = depth - 1; lvl >= 0; --lvl) {
-        if (lvl != depth - 1) kid = sum[(long)offs.off[lvl] + (long)node * RADIX + lane];
-        float incl = wave_scan_incl(kid, lane);
-        bool hit = (incl >= v) && (kid > 0.f);
-        unsigned long long mask = __ballot(hit);
-        int pick;
-        if (mask) {
-            pick = __ffsll((long long)mask) - 1;
-        } else {                                    // rounding pushed v past the end: last positive child
-            unsigned long long pos = __ballot(kid > 0.f);
-            pick = pos ? 63 - __clzll((long long)pos) : 0;
-        }
-        float excl = __shfl(incl - kid, pick, 64);
-        v -= excl;
-        node = node * RADIX + pick;
-    }
-    node = min(node, num_leaves - 1);
-    if (lane == 0) {
-        float p = sum[node];
-        out_idx[wave] = node;
-        // (min tree of an empty / partly filled tree holds +inf in its unused leaves: a tree with no positive
-        // leaf at all gives weight 1 instead of inf^beta)
-        const float ratio = (pmin < 3.0e38f && p > 0.f) ? pmin / p : 1.f;
-        out_w[wave] = __powf(ratio, beta);
-    }
+    segtree_sample_wave(sum, mn, offs, depth, num_leaves, u, wave, lane, B, beta, out_idx, out_w, ntop, sum_w, mn_w);
 }
 // ntop: nodes of the top level (re-derived from the level below by every wave and written back); 0 = read it as stored
 PDA_EXPORT void pda_segtree_sample(void* sum, void* mn, const int* offs, int depth, int num_leaves,

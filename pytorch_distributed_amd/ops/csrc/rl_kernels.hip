@@ -384,7 +384,7 @@ PDA_EXPORT void pda_adam(void* p, void* g, void* m, void* v, void* shadow, const
 PDA_EXPORT void pda_adam_x(void* p, void* g, void* m, void* v, void* shadow, const void* segs, const void* chunks,
                            int nchunks, const void* hyper, void* step, const AdamExtras* extras, hipStream_t stream) {
     AdamExtras x = *extras;
-    int extra_blocks = adam_sampler_blocks(x) + adam_repair_blocks(x);
+    int extra_blocks = adam_sampler_blocks(x) + adam_repair_blocks(x) + adam_per_sampler_blocks(x);
     hipLaunchKernelGGL(adam_kernel, dim3(nchunks + extra_blocks), dim3(256), 0, stream, (float*)p, (float*)g,
                        (float*)m, (float*)v, (bf16_t*)shadow, (const SegEntry*)segs, (const int2*)chunks, nchunks,
                        (const float*)hyper, (const int*)step, x);

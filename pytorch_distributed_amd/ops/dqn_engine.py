@@ -256,7 +256,7 @@ class DqnCnnEngine(object):
         x = AdamExtras()
         if slabs:
             x.slab, x.slabinfo = self.slab.data_ptr(), self.slabinfo.data_ptr()
-        if self.presamples(staged):
+        if self.presamples(staged) and not self._per_bound():
             x.next_idx, x.next_w, x.next_B = self.idx.data_ptr(), self.isw.data_ptr(), self.B
             x.size, x.seed, x.counter = self.size_dev.data_ptr(), self.seed, self.counter.data_ptr()
         tree = self.replay[3] if (self.replay is not None and not staged and self.per is not None) else None
@@ -267,14 +267,35 @@ class DqnCnnEngine(object):
             # from post_update() and their top level re-derived by the next step's sampling kernel (tree.lazy_top)
             x.rep_sum, x.rep_min, x.rep_idx = tree.sum.data_ptr(), tree.min.data_ptr(), self.idx.data_ptr()
             x.rep_n, x.rep_parent_off = self.B, int(tree.offsets[1])
-            if tree.depth == 3:
-                if getattr(self, "_rep_count", None) is None:
-                    self._rep_count = torch.zeros(1, dtype=torch.int32, device=self.device)
-                x.rep_count, x.rep_top_off, x.rep_top_n = self._rep_count.data_ptr(), int(tree.offsets[2]), int(tree.sizes[2])
+            if tree.depth <= 3:
+                if getattr(self, "_rep_sync", None) is None:
+                    self._rep_sync = torch.zeros(4, dtype=torch.int32, device=self.device)     # arrivals | done | arrivals
+                x.rep_count = self._rep_sync.data_ptr()
+                if tree.depth == 3:
+                    x.rep_top_off, x.rep_top_n = int(tree.offsets[2]), int(tree.sizes[2])
+                if self.presamples(staged):
+                    # ... and the next step's prioritized draw behind the repair, in the same launch
+                    x.ps_idx, x.ps_w, x.ps_B = self.idx.data_ptr(), self.isw.data_ptr(), self.B
+                    x.ps_depth, x.ps_leaves, x.ps_beta = tree.depth, tree.num_leaves, float(self.per["beta"])
+                    for i, o in enumerate(tree.offsets):
+                        x.ps_offs[i] = int(o)
+                    x.ps_done, x.ps_count = self._rep_sync.data_ptr() + 4, self._rep_sync.data_ptr() + 8
+                    x.seed, x.counter = self.seed, self.counter.data_ptr()
         return x
 
+    def _per_bound(self):
+        return self.replay is not None and self.replay[3] is not None and self.per is not None
+
     def presamples(self, staged):
-        return (not staged) and self.replay is not None and not (self.replay[3] is not None and self.per is not None)
+        """True when the optimizer launch of a step also draws the next step's replay rows: uniform sampling from
+        device replay, or prioritized sampling from a native tree of up to three levels (<= 262 k leaves), which that
+        launch also repairs completely (fused_extras)."""
+        if staged or self.replay is None:
+            return False
+        if not self._per_bound():
+            return True
+        tree = self.replay[3]
+        return bool(getattr(tree, "native", False)) and 2 <= tree.depth <= 3
 
     def backward_conv(self, staged=False, reduce=True):
         """reduce: sum the split-K slabs with a launch of their own (data parallel: the all-reduce needs the sums);

@@ -184,8 +184,8 @@ class DqnStepProgram(object):
         e.adam.step(table=self.tail_table)          # fc tail update runs under the conv all-reduce
         mark("wait_head", cur)
         cur.wait_event(self.head_done)
-        e.adam.step(table=self.head_table, extras=self.dp_extras)     # + next step's index draw
-        e.post_update(self.staged)
+        e.adam.step(table=self.head_table, extras=self.dp_extras)     # + next step's index draw (+ tree repair)
+        e.post_update(self.staged, repair_from=2 if (self.dp_extras is not None and self.dp_extras.rep_sum) else 1)
         mark("step1", cur)
         self.presampled = self.dp_extras is not None
 

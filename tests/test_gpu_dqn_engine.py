@@ -193,7 +193,7 @@ def test_device_replay_uniform_and_per_steps(eng):
     from pytorch_distributed_amd.utils.options import Options
     from pytorch_distributed_amd.launcher import prepare_options
     for cfg in (2, 4):
-        opt = prepare_options(Options(config=cfg, overrides={"memory_params.memory_size": 4096,
+        opt = prepare_options(Options(config=cfg, overrides={"memory_params.memory_size": 4096, "graph_steps": 1,
                                                              "agent_params.batch_size": 64}))
         mem = DeviceMemory(opt.memory_params)
         mem.attach(torch.device("cuda"))
@@ -205,10 +205,16 @@ def test_device_replay_uniform_and_per_steps(eng):
                        priorities=torch.rand(n, device="cuda") + 0.1)
         model, target = make_models()
         core = eng.DqnNativeCore(opt, model, target, mem)
-        for _ in range(6):
+        for _ in range(5):
             core.step()
         torch.cuda.synchronize()
-        idx = core.engine.idx.cpu().numpy()
+        # (the optimizer launch of an update also draws the next update's rows: the rows of the sixth update are
+        # what the engine holds after the fifth)
+        assert core.engine.presamples(False)
+        idx_last = core.engine.idx.clone()
+        core.step()
+        torch.cuda.synchronize()
+        idx = idx_last.cpu().numpy()
         assert idx.min() >= 0 and idx.max() < n, (idx.min(), idx.max())
         assert len(np.unique(idx)) > 16
         loss = core.loss_values()["critic_loss"]
@@ -217,7 +223,7 @@ def test_device_replay_uniform_and_per_steps(eng):
             tree = mem.tree
             leaves = tree.sum[:n]
             want = (core.engine.td.abs() + mem.priority_eps) ** mem.priority_exponent
-            got = leaves[core.engine.idx.long()]
+            got = leaves[idx_last.long()]
             # duplicates inside a batch may have been written by either sample
             close = (got - want).abs() < 1e-3 * (1 + want.abs())
             assert close.float().mean().item() > 0.9

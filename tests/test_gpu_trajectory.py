@@ -170,15 +170,22 @@ def test_prioritized_trajectory_matches_torch_on_the_rows_the_engine_drew(eng):
     e.bind_replay(s0, s1, tails, tree)
     e.set_size(n)
     prog = eng.DqnStepProgram(e, None, use_graph=True, staged=False, graph_steps=1)
+    # The optimizer launch of a step also repairs the tree and draws the NEXT step's rows (trees of <= 3 levels), so
+    # the rows of a step are what e.idx holds BEFORE it runs; the very first draw is made here instead of inside it.
+    assert e.presamples(False)
+    e.sample()
+    prog.presampled = True
     for t in range(steps):
+        torch.cuda.synchronize()
+        idx_t = e.idx.clone()
+        rows, w = idx_t.cpu().tolist(), e.isw.clone()
         prog.step()
         torch.cuda.synchronize()
-        rows, w = e.idx.cpu().tolist(), e.isw.clone()
         assert 0 <= min(rows) and max(rows) < n and float(w.max()) <= 1.0 + 1e-6 and float(w.min()) > 0
         td = ref.step(s0, s1, tails, rows, w)
         # priorities written back: leaf = (|td| + eps)^alpha of the engine's own TD error
         want = (e.td.abs() + per["eps"]) ** per["alpha"]
-        got = tree.sum[e.idx.long()]
+        got = tree.sum[idx_t.long()]
         assert ((got - want).abs() < 1e-5 * (1 + want)).float().mean().item() > 0.95   # duplicates: either writer
         assert (e.td - td).abs().max().item() < 5e-3 * max(1.0, td.abs().max().item()), t
     d = drift(e.online.flat, ref.flat(), init)
