@@ -56,7 +56,9 @@ struct AdamExtras {
     // trees of three levels: the last repair block to finish also recomputes the rep_top_n nodes of the top level
     // (at rep_top_off) from the repaired level, so such a tree is complete when this launch ends.  rep_count: a
     // device int, zero between launches.  rep_top_n == 0 = off
-    int* rep_count; int rep_top_off; int rep_top_n;
+    // (the level offsets and the depth come from ps_offs / ps_depth below); rep_bar: barrier counter of the repair
+    // blocks (trees of four levels), zero between launches
+    int* rep_count; int rep_top_off; int rep_top_n; int* rep_bar;
     // ... and the NEXT step's prioritized draw rides behind it (trees of up to three levels, complete once the last
     // repair block has finished): ps_B sampler waves, four per block, wait for that block's flag *ps_done (bounded
     // spin), then descend the tree rep_sum / rep_min exactly as segtree_sample_kernel does (uniforms from seed and
@@ -179,46 +181,77 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
     }
     if (bid >= nchunks + adam_sampler_blocks(x)) {      // tree-repair blocks (only launched when x.rep_sum is set)
         const int wave = (bid - nchunks - adam_sampler_blocks(x)) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-        if (wave < x.rep_n) {
-            const int node = x.rep_idx[wave] >> 6;
-            const long child = (long)node * 64 + lane;          // level 0 starts at offset 0
-            const float s = wave_sum(x.rep_sum[child]);
-            const float q = wave_min(x.rep_min[child]);
-            if (lane == 0) {
-                if (x.rep_count) {
-                    const float r0 = atomicExch(x.rep_sum + x.rep_parent_off + node, s);
-                    const float r1 = atomicExch(x.rep_min + x.rep_parent_off + node, q);
-                    asm volatile("" :: "v"(r0), "v"(r1));       // both exchanges have returned: the nodes are in place
-                } else {
+        if (!x.rep_count) {         // level 1 only (deeper trees: the caller repairs the rest, tree.lazy_top)
+            if (wave < x.rep_n) {
+                const int node = x.rep_idx[wave] >> 6;
+                const long child = (long)node * 64 + lane;      // level 0 starts at offset 0
+                const float s = wave_sum(x.rep_sum[child]);
+                const float q = wave_min(x.rep_min[child]);
+                if (lane == 0) {
                     x.rep_sum[x.rep_parent_off + node] = s;
                     x.rep_min[x.rep_parent_off + node] = q;
                 }
             }
+            return;
         }
-        if (x.rep_count) {
-            int* last = reinterpret_cast<int*>(row);
-            __syncthreads();                                    // this block's nodes are stored
-            if (threadIdx.x == 0) {
-                const int prev = atomicAdd(x.rep_count, 1);
-                *last = prev + 1 == adam_repair_blocks(x) ? 1 : 0;
-                if (*last) __hip_atomic_store(x.rep_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The whole tree (2 .. 4 levels).  Levels 1 .. L are repaired per sampled row, a wave per row and level, with a
+        // barrier of the repair blocks between two levels (they are few and all resident); the last block to finish
+        // recomputes every node of the top level and releases the sampler blocks.
+        int* flag = reinterpret_cast<int*>(row);
+        const int L = x.ps_depth <= 2 ? 1 : x.ps_depth - 2;
+        for (int lvl = 1; lvl <= L; ++lvl) {
+            if (wave < x.rep_n) {
+                const int node = x.rep_idx[wave] >> (6 * lvl);
+                const long child = (long)x.ps_offs.off[lvl - 1] + (long)node * 64 + lane;
+                float cs, cm;
+                if (lvl == 1) { cs = x.rep_sum[child]; cm = x.rep_min[child]; }       // leaves: an earlier launch's
+                else {
+                    cs = __hip_atomic_load(x.rep_sum + child, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cm = __hip_atomic_load(x.rep_min + child, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const float s = wave_sum(cs), q = wave_min(cm);
+                if (lane == 0) {
+                    const float r0 = atomicExch(x.rep_sum + x.ps_offs.off[lvl] + node, s);
+                    const float r1 = atomicExch(x.rep_min + x.ps_offs.off[lvl] + node, q);
+                    asm volatile("" :: "v"(r0), "v"(r1));       // both exchanges have returned: the node is in place
+                }
             }
-            __syncthreads();
-            if (*last) {                                        // every repair block has published its nodes
-                for (int j = threadIdx.x >> 6; j < x.rep_top_n; j += 4) {
-                    const long child = (long)x.rep_parent_off + (long)j * 64 + lane;
-                    const float s = wave_sum(__hip_atomic_load(x.rep_sum + child, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    const float q = wave_min(__hip_atomic_load(x.rep_min + child, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    if (lane == 0) {
-                        const float r0 = atomicExch(x.rep_sum + x.rep_top_off + j, s);
-                        const float r1 = atomicExch(x.rep_min + x.rep_top_off + j, q);
-                        asm volatile("" :: "v"(r0), "v"(r1));
-                    }
+            if (lvl < L) {          // barrier of the repair blocks (x.rep_bar: reset by the last block of the launch)
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    atomicAdd(x.rep_bar, 1);
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(x.rep_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+                               (lvl * adam_repair_blocks(x)) && ++spins < (1u << 22))
+                        __builtin_amdgcn_s_sleep(2);
                 }
-                if (x.ps_done) {                                // the tree is complete: release the sampler blocks
-                    __syncthreads();
-                    if (threadIdx.x == 0) __hip_atomic_store(x.ps_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+            }
+        }
+        __syncthreads();                                        // this block's nodes are stored
+        if (threadIdx.x == 0) {
+            const int prev = atomicAdd(x.rep_count, 1);
+            *flag = prev + 1 == adam_repair_blocks(x) ? 1 : 0;
+            if (*flag) {
+                __hip_atomic_store(x.rep_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(x.rep_bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        if (*flag) {                                            // every repair block has published its nodes
+            for (int j = threadIdx.x >> 6; j < x.rep_top_n; j += 4) {
+                const long child = (long)x.ps_offs.off[x.ps_depth - 2] + (long)j * 64 + lane;
+                const float s = wave_sum(__hip_atomic_load(x.rep_sum + child, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const float q = wave_min(__hip_atomic_load(x.rep_min + child, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (lane == 0) {
+                    const float r0 = atomicExch(x.rep_sum + x.rep_top_off + j, s);
+                    const float r1 = atomicExch(x.rep_min + x.rep_top_off + j, q);
+                    asm volatile("" :: "v"(r0), "v"(r1));
                 }
+            }
+            if (x.ps_done) {                                    // the tree is complete: release the sampler blocks
+                __syncthreads();
+                if (threadIdx.x == 0) __hip_atomic_store(x.ps_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         return;

@@ -267,18 +267,20 @@ class DqnCnnEngine(object):
             # from post_update() and their top level re-derived by the next step's sampling kernel (tree.lazy_top)
             x.rep_sum, x.rep_min, x.rep_idx = tree.sum.data_ptr(), tree.min.data_ptr(), self.idx.data_ptr()
             x.rep_n, x.rep_parent_off = self.B, int(tree.offsets[1])
-            if tree.depth <= 3:
+            if tree.depth <= 4:
                 if getattr(self, "_rep_sync", None) is None:
-                    self._rep_sync = torch.zeros(4, dtype=torch.int32, device=self.device)     # arrivals | done | arrivals
-                x.rep_count = self._rep_sync.data_ptr()
-                if tree.depth == 3:
-                    x.rep_top_off, x.rep_top_n = int(tree.offsets[2]), int(tree.sizes[2])
+                    # arrivals | sampler release flag | sampler arrivals | barrier of the repair blocks
+                    self._rep_sync = torch.zeros(4, dtype=torch.int32, device=self.device)
+                x.rep_count, x.rep_bar = self._rep_sync.data_ptr(), self._rep_sync.data_ptr() + 12
+                x.ps_depth, x.ps_leaves = tree.depth, tree.num_leaves
+                for i, o in enumerate(tree.offsets):
+                    x.ps_offs[i] = int(o)
+                if tree.depth >= 3:
+                    x.rep_top_off, x.rep_top_n = int(tree.offsets[tree.depth - 1]), int(tree.sizes[tree.depth - 1])
                 if self.presamples(staged):
                     # ... and the next step's prioritized draw behind the repair, in the same launch
                     x.ps_idx, x.ps_w, x.ps_B = self.idx.data_ptr(), self.isw.data_ptr(), self.B
-                    x.ps_depth, x.ps_leaves, x.ps_beta = tree.depth, tree.num_leaves, float(self.per["beta"])
-                    for i, o in enumerate(tree.offsets):
-                        x.ps_offs[i] = int(o)
+                    x.ps_beta = float(self.per["beta"])
                     x.ps_done, x.ps_count = self._rep_sync.data_ptr() + 4, self._rep_sync.data_ptr() + 8
                     x.seed, x.counter = self.seed, self.counter.data_ptr()
         return x
@@ -288,14 +290,14 @@ class DqnCnnEngine(object):
 
     def presamples(self, staged):
         """True when the optimizer launch of a step also draws the next step's replay rows: uniform sampling from
-        device replay, or prioritized sampling from a native tree of up to three levels (<= 262 k leaves), which that
+        device replay, or prioritized sampling from a native tree of up to four levels (<= 16.7 M leaves), which that
         launch also repairs completely (fused_extras)."""
         if staged or self.replay is None:
             return False
         if not self._per_bound():
             return True
         tree = self.replay[3]
-        return bool(getattr(tree, "native", False)) and 2 <= tree.depth <= 3
+        return bool(getattr(tree, "native", False)) and 2 <= tree.depth <= 4
 
     def backward_conv(self, staged=False, reduce=True):
         """reduce: sum the split-K slabs with a launch of their own (data parallel: the all-reduce needs the sums);
@@ -384,16 +386,19 @@ class DqnCnnEngine(object):
     def update(self, staged=False, tick=False, extras=None):
         """tick: bump Adam's step counter here (the head kernel does it in a full step)."""
         self.adam.step(tick=tick, extras=extras)
-        self.post_update(staged, repair_from=2 if (extras is not None and extras.rep_sum) else 1)
+        fused = extras is not None and bool(extras.rep_sum)
+        self.post_update(staged, repair_from=(0 if extras.rep_count else 2) if fused else 1)
 
     def post_update(self, staged=False, repair_from=1):
-        """What follows the optimizer: soft target update, sum/min-tree repair of the sampled leaves (repair_from = 2:
-        level 1 was repaired inside the optimizer launch and the sampling kernel re-derives the top level)."""
+        """What follows the optimizer: soft target update, sum/min-tree repair of the sampled leaves (repair_from = 0:
+        the optimizer launch repaired the whole tree; 2: only level 1, and the sampling kernel re-derives the top)."""
         if self.target_update < 1.0:
             self._target_copy(self.target_update)
         if not staged and self.per is not None and self.replay[3] is not None:
             tree = self.replay[3]
-            if repair_from == 2:
+            if repair_from == 0:
+                pass                # the optimizer launch repaired the whole tree (csrc/optim.h)
+            elif repair_from == 2:
                 tree.repair(self.idx, self.B, first_level=2, stop_level=tree.depth - 1)
             else:
                 tree.repair(self.idx, self.B)

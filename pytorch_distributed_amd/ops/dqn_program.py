@@ -185,7 +185,8 @@ class DqnStepProgram(object):
         mark("wait_head", cur)
         cur.wait_event(self.head_done)
         e.adam.step(table=self.head_table, extras=self.dp_extras)     # + next step's index draw (+ tree repair)
-        e.post_update(self.staged, repair_from=2 if (self.dp_extras is not None and self.dp_extras.rep_sum) else 1)
+        x = self.dp_extras
+        e.post_update(self.staged, repair_from=((0 if x.rep_count else 2) if (x is not None and x.rep_sum) else 1))
         mark("step1", cur)
         self.presampled = self.dp_extras is not None
 

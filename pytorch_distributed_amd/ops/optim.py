@@ -72,7 +72,7 @@ class AdamExtras(ctypes.Structure):     # mirrors AdamExtras in csrc/rl_kernels.
                 ("tinfo", _vp), ("tgt", _vp), ("tgt_shadow", _vp), ("tau", ctypes.c_float),
                 ("rep_sum", _vp), ("rep_min", _vp), ("rep_idx", _vp), ("rep_n", ctypes.c_int),
                 ("rep_parent_off", ctypes.c_int), ("rep_count", _vp), ("rep_top_off", ctypes.c_int),
-                ("rep_top_n", ctypes.c_int),
+                ("rep_top_n", ctypes.c_int), ("rep_bar", _vp),
                 ("ps_idx", _vp), ("ps_w", _vp), ("ps_B", ctypes.c_int), ("ps_depth", ctypes.c_int),
                 ("ps_leaves", ctypes.c_int), ("ps_beta", ctypes.c_float), ("ps_offs", ctypes.c_int * 8),
                 ("ps_done", _vp), ("ps_count", _vp)]
