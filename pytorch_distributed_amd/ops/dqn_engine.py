@@ -267,7 +267,7 @@ class DqnCnnEngine(object):
             # from post_update() and their top level re-derived by the next step's sampling kernel (tree.lazy_top)
             x.rep_sum, x.rep_min, x.rep_idx = tree.sum.data_ptr(), tree.min.data_ptr(), self.idx.data_ptr()
             x.rep_n, x.rep_parent_off = self.B, int(tree.offsets[1])
-            if tree.depth <= 4:
+            if self._tree_in_optimizer_launch(tree):
                 if getattr(self, "_rep_sync", None) is None:
                     # arrivals | sampler release flag | sampler arrivals | barrier of the repair blocks
                     self._rep_sync = torch.zeros(4, dtype=torch.int32, device=self.device)
@@ -288,6 +288,12 @@ class DqnCnnEngine(object):
     def _per_bound(self):
         return self.replay is not None and self.replay[3] is not None and self.per is not None
 
+    def _tree_in_optimizer_launch(self, tree):
+        """Whole-tree repair + the next step's draw as blocks of the optimizer launch: trees of up to four levels and
+        batches whose repair and sampler blocks (B / 4 each) are resident together with the optimizer's own -- at batch
+        4096 they are not, and the blocks that wait for each other serialise the launch (1.61 -> 1.67 ms per step)."""
+        return bool(getattr(tree, "native", False)) and 2 <= tree.depth <= 4 and self.B <= 512
+
     def presamples(self, staged):
         """True when the optimizer launch of a step also draws the next step's replay rows: uniform sampling from
         device replay, or prioritized sampling from a native tree of up to four levels (<= 16.7 M leaves), which that
@@ -296,8 +302,7 @@ class DqnCnnEngine(object):
             return False
         if not self._per_bound():
             return True
-        tree = self.replay[3]
-        return bool(getattr(tree, "native", False)) and 2 <= tree.depth <= 4
+        return self._tree_in_optimizer_launch(self.replay[3])
 
     def backward_conv(self, staged=False, reduce=True):
         """reduce: sum the split-K slabs with a launch of their own (data parallel: the all-reduce needs the sums);
