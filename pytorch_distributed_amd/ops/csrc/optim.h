@@ -239,15 +239,28 @@ __device__ __forceinline__ void adam_block(float* __restrict__ p, float* __restr
         }
         __syncthreads();
         if (*flag) {                                            // every repair block has published its nodes
-            for (int j = threadIdx.x >> 6; j < x.rep_top_n; j += 4) {
-                const long child = (long)x.ps_offs.off[x.ps_depth - 2] + (long)j * 64 + lane;
-                const float s = wave_sum(__hip_atomic_load(x.rep_sum + child, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                const float q = wave_min(__hip_atomic_load(x.rep_min + child, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (lane == 0) {
-                    const float r0 = atomicExch(x.rep_sum + x.rep_top_off + j, s);
-                    const float r1 = atomicExch(x.rep_min + x.rep_top_off + j, q);
-                    asm volatile("" :: "v"(r0), "v"(r1));
+            // top level: wave w takes nodes w, w + 4, ...; four rows in flight per wave (13 nodes for 50 k leaves: one
+            // memory round trip -- one row at a time put four of them on the step's critical path)
+            const long below = (long)x.ps_offs.off[x.ps_depth - 2];
+            for (int j0 = threadIdx.x >> 6; j0 < x.rep_top_n; j0 += 16) {
+                float cs[4], cm[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int j = min(j0 + 4 * t, x.rep_top_n - 1);
+                    cs[t] = __hip_atomic_load(x.rep_sum + below + (long)j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cm[t] = __hip_atomic_load(x.rep_min + below + (long)j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                float r = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float s = wave_sum(cs[t]), q = wave_min(cm[t]);
+                    const int j = j0 + 4 * t;
+                    if (lane == 0 && j < x.rep_top_n) {
+                        r += atomicExch(x.rep_sum + x.rep_top_off + j, s);
+                        r += atomicExch(x.rep_min + x.rep_top_off + j, q);
+                    }
+                }
+                asm volatile("" :: "v"(r));                     // every exchange has returned
             }
             if (x.ps_done) {                                    // the tree is complete: release the sampler blocks
                 __syncthreads();
