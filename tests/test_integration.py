@@ -96,6 +96,21 @@ def test_frame_deduplicated_replay_whole_job(tmp_root):
     assert st["transitions"] >= 40 and st["planes_per_transition"] < 3.0 and st["rows_in_window"] > 0
 
 
+def test_dead_actor_on_frame_deduplicated_replay_is_restarted_and_the_job_finishes(tmp_root):
+    """An actor that dies takes its open run (and possibly a claimed ring slot) with it: the supervisor restarts it, its
+    new n-step assemblers start new runs, and the learner keeps ingesting the other streams' runs meanwhile."""
+    opt = opts(2, tmp_root, num_actors=2, num_envs_per_actor=2, timestamp="dedupfault", memory_type="device-dedup",
+               inject_fault="actor:1@30",
+               **{"agent_params.steps": 40, "agent_params.learn_start": 60, "agent_params.batch_size": 8,
+                  "memory_params.memory_size": 256, "memory_params.dedup_plane_cap": 32,
+                  "memory_params.dedup_max_age_ms": 200, "memory_params.dedup_chunk_runs": 2})
+    sup = run(opt)
+    assert sup.restarts == 1
+    assert os.path.exists(opt.model_name)
+    steps = [s["step"] for s in read_scalars(opt.log_dir)]
+    assert max(steps) >= 40
+
+
 def test_supervisor_restarts_dead_actor(tmp_root):
     opt = opts(6, tmp_root, inject_fault="actor:1@15", **{"agent_params.steps": 150})
     sup = run(opt)
