@@ -319,9 +319,12 @@ __global__ __launch_bounds__(PAR_THREADS) void peer_allreduce_kernel(PeerArArgs 
     }
 
     // ---- the last workgroup to finish closes the call: epoch += 1 ------------------------------------------------
+    // (No fence here: the gradient written above is read by LATER kernels of this stream, which the end of this one
+    // orders; an agent-scope fence would write back the L2 -- full of the concurrent backward kernels' dirty lines --
+    // once per workgroup.  The epoch bump below only has to follow every workgroup's READ of the epoch, and a workgroup
+    // counts itself done after that read.)
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
         const unsigned prev = atomicAdd(&me->done, 1u);
         if (prev + 1u == gridDim.x) {
             me->done = 0u;
