@@ -231,6 +231,11 @@ def fc1_slabs(acts, geom, B, groups, device):
     mult = 1        # (split operands: the x3 GEMM body reduces over the logical K, csrc/gemm.h gemm_body_x3)
     tiles = ((B + 63) // 64) * (g.HID // 64) * groups
     ks = _ksplit(mult * g.F, tiles, acts.fc1_blocks, 128)
+    if device.type == "cuda" and nn.gemm_large_tiles(B, g.HID, groups):
+        # large batches: 128 x 128 tiles, two workgroups per CU -- with one, too few loads are in flight per CU
+        # (batch 4096: 47 -> 43 us bf16, 99 -> 92 us split-bf16 with two slices; four: 58 / 117 us)
+        big_tiles = ((B + 127) // 128) * ((g.HID + 127) // 128) * groups
+        ks = _ksplit(mult * g.F, big_tiles, 2 * acts.fc1_blocks, 128)
     acts.h1_ksplit = ks
     acts.h1_slices = nn.num_slices(mult * g.F, ks)
     acts.h1pre = [torch.zeros(acts.h1_slices, B, g.HID, dtype=torch.float32, device=device) for _ in range(groups)]

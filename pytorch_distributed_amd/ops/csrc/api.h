@@ -24,6 +24,8 @@ PDA_EXPORT void pda_conv_fwd(const void* const* x, const void* const* w, const v
 PDA_EXPORT void pda_linear_fwd(const void* const* x, const void* const* w, const void* const* bias,
                                void* const* out, void* const* out32, int ngroups, int M, int N, int K,
                                long ldx, long ldw, long ldo, long ldo32, int act, int ksplit, hipStream_t stream);
+// tile choice of the GEMM entry points (gemm.hip): 0 = 64 x 64, else the large-tile variant for this problem
+PDA_EXPORT int pda_gemm_large_tiles(int M, int N, int units, int best);
 PDA_EXPORT void pda_act_head(const ActHeadArgs* args, hipStream_t stream);
 PDA_EXPORT void pda_tick(void* step, void* counter, hipStream_t stream);
 PDA_EXPORT void pda_mlp_stage(const StageJobs* jobs, int njobs, const void* idx, int B, int max_cols,

@@ -529,7 +529,10 @@ __device__ __forceinline__ int swz_n(int r) {
 template <int ROWS>
 __device__ __forceinline__ int swz_t(int kk) {
     if (ROWS == 32) return ((kk >> 3) & 1) << 2;
-    return (((kk >> 1) & 1) | (((kk >> 3) & 1) << 1)) << 2;          // ROWS == 64
+    if (ROWS == 64) return (((kk >> 1) & 1) | (((kk >> 3) & 1) << 1)) << 2;
+    // ROWS == 128: a k-row is one whole 256-byte bank row, so the 8 k-rows of a 32-lane half (k & 3, bit 3 of k)
+    // all start at bank 0: each goes to a 4-chunk group of its own
+    return ((kk & 3) | (((kk >> 3) & 1) << 2)) << 2;
 }
 
 template <bool T, int ROWS, int BK>
@@ -540,7 +543,7 @@ struct LdsShape {
 template <bool T, int ROWS, int BK, class SRC>
 struct Stager {
     static_assert(BK == 32 || BK == 64, "k-tile of 32 or 64");
-    static_assert(ROWS == 32 || ROWS == 64, "tile side of 32 or 64");
+    static_assert(ROWS == 32 || ROWS == 64 || ROWS == 128, "tile side of 32, 64 or 128");
     static constexpr int kItems = ROWS * BK / 8;
     static constexpr int kIters = (kItems + GEMM_THREADS - 1) / GEMM_THREADS;
     typename SRC::Ctx ctx[kIters];

@@ -16,8 +16,29 @@ bool small_grid(int M, int N, int groups) {
 }
 
 int g_force_generic_conv1 = 0;
+int g_tile_mode = 0;
 
 }  // namespace
+
+// Large problems (batch 4096: fc1 forward 8192 x 512 x 3136) run on 128-row tiles.  A 64 x 64 launch is bound by the
+// rate at which a CU pulls operand bytes through its L1 (822 MB in 66 us = 12.4 TB/s over the chip for that forward,
+// and the split-bf16 launch moves the same bytes per second): the way up is fewer operand bytes per FLOP, half of them
+// per doubling of the tile side.  Measured at batch 4096 (tools/probes/gemm_tiles_bench.py, profiles/r3_gemm_tiles.txt):
+//   fc1 forward    bf16 66 -> 47 us (128 x 128, k-tile 32; k-tile 64 leaves one wave per SIMD: 52 us), two k-slices 43 us
+//                  split-bf16 136 -> 99 us (128 x 128, k-tile 32: four planes of a k-tile in 64 KB), two slices 92 us
+//   fc1 data grad  bf16 56 -> 61 / 92 us: kept on 64 x 64 (8 k-tiles per workgroup, then a 2-byte-per-lane epilogue
+//                  that nothing overlaps at one or two workgroups per CU); split-bf16 103 -> 95 us on 128 x 64
+// pda_gemm_tile_mode (test / measurement hook): 0 = the rule below, 1 = 64 x 64 tiles only, 2 / 3 = a large-tile
+// variant whenever both sides reach 128 (bf16: 128 x 128; split operands: 2 = 128 x 128, 3 = 128 x 64).
+PDA_EXPORT void pda_gemm_tile_mode(int mode) { g_tile_mode = mode; }
+// -> 0: 64 x 64 tiles; otherwise the large-tile variant to use.  best = the call site's measured best variant (0: none),
+// taken when its 128 x 128 grid still gives nearly every CU a workgroup.
+PDA_EXPORT int pda_gemm_large_tiles(int M, int N, int units, int best) {
+    if (g_tile_mode == 1 || M < 128 || N < 128) return 0;
+    if (g_tile_mode >= 2) return g_tile_mode;
+    long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * units;
+    return tiles >= 224 ? best : 0;
+}
 
 // test hook (tests/test_gpu_gemm.py, ops/nn.py:force_generic_conv1): run the Nature conv1 geometry through the generic
 // implicit-GEMM loaders instead of the whole-image kernels
@@ -116,7 +137,10 @@ PDA_EXPORT void pda_linear_fwd_slab(const void* const* x, const void* const* w, 
     int units = grid.y * grid.z;
     if (units < 8) {    // fewer (slice, group) units than XCDs (large batches: one slice): the unit-per-XCD order would
         // leave XCDs idle (batch 4096: 196 us on 2 of the 8 XCDs against 70 us in plain order)
-        launch_gemm<64, 64, 2, 2>(a, ngroups, M, N, K, ksplit > 0 ? ksplit : K, stream);
+        if (pda_gemm_large_tiles(M, N, units, 2))
+            launch_gemm<128, 128, 2, 2, SrcDenseK, SrcDenseK, EpiSlabF32, 32>(a, ngroups, M, N, K, ksplit > 0 ? ksplit : K, stream);
+        else
+            launch_gemm<64, 64, 2, 2>(a, ngroups, M, N, K, ksplit > 0 ? ksplit : K, stream);
         return;
     }
     hipLaunchKernelGGL((gemm_xcd_kernel<64, 64, 2, 2, GEMM_BK, SrcDenseK, SrcDenseK, EpiSlabF32>),
@@ -133,7 +157,9 @@ PDA_EXPORT void pda_linear_dgrad(const void* dy, const void* w, const void* y, v
     a.g[0].e = {(bf16_t*)dx, (const bf16_t*)y, y ? act : ACT_NONE, lddx, ldy};
     a.g[0].M = M; a.g[0].N = Kin; a.g[0].K = Nout;
     // under-filled launches (fc1 dgrad at batch 128: 98 tiles of 64x64 for 256 CUs) take the 32-row tile
-    if (M <= 32 || small_grid(M, Kin, 1)) launch_gemm<32, 64, 1, 4>(a, 1, M, Kin, Nout, 0, stream);
+    if (pda_gemm_large_tiles(M, Kin, 1, 0))      // (not chosen by the size rule: see the measurements above)
+        launch_gemm<128, 128, 2, 2, SrcDenseK, SrcDenseT, EpiMaskBf16, 32>(a, 1, M, Kin, Nout, 0, stream);
+    else if (M <= 32 || small_grid(M, Kin, 1)) launch_gemm<32, 64, 1, 4>(a, 1, M, Kin, Nout, 0, stream);
     else launch_gemm<64, 64, 2, 2>(a, 1, M, Kin, Nout, 0, stream);
 }
 

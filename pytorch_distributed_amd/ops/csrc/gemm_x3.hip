@@ -90,7 +90,11 @@ PDA_EXPORT void pda_x3_linear_fwd(const void* const* x, long x_plane, const void
         int units = grid.y * grid.z;
         if (units < 8) {    // fewer (slice, group) units than XCDs (large batches: one slice): the unit-per-XCD order would
             // leave XCDs idle (batch 4096: 196 us on 2 of the 8 XCDs against 70 us in plain order)
-            launch_gemm<64, 64, 2, 2>(a, ngroups, M, N, K, ksplit > 0 ? ksplit : K, stream);
+            // large problems: 128-row tiles with a k-tile of 32 (four planes of a k-tile in 64 KB of LDS), see gemm.hip
+            const int big = pda_gemm_large_tiles(M, N, units, 2);
+            if (big == 3) launch_gemm<128, 64, 2, 2, SA, SB, EpiSlabF32, 32>(a, ngroups, M, N, K, ksplit > 0 ? ksplit : K, stream);
+            else if (big) launch_gemm<128, 128, 2, 2, SA, SB, EpiSlabF32, 32>(a, ngroups, M, N, K, ksplit > 0 ? ksplit : K, stream);
+            else launch_gemm<64, 64, 2, 2>(a, ngroups, M, N, K, ksplit > 0 ? ksplit : K, stream);
             return;
         }
         hipLaunchKernelGGL((gemm_xcd_kernel<64, 64, 2, 2, GEMM_BK, SA, SB, EpiSlabF32>),
@@ -111,12 +115,17 @@ PDA_EXPORT void pda_x3_linear_fwd(const void* const* x, long x_plane, const void
 PDA_EXPORT void pda_x3_linear_dgrad(const void* dy, long dy_plane, const void* w, long w_plane, const void* y,
                                     void* dx, long dx_plane, int M, int Nout, int Kin, long lddy, long ldw, long ldy,
                                     long lddx, int act, hipStream_t stream) {
-    GemmArgs<SPLIT_A3(SrcDenseK), SPLIT_B3(SrcDenseT), EpiMaskBf16> a;
+    typedef SPLIT_A3(SrcDenseK) SA;
+    typedef SPLIT_B3(SrcDenseT) SB;
+    GemmArgs<SA, SB, EpiMaskBf16> a;
     a.g[0].a = {{(const bf16_t*)dy, lddy, M, Nout}, dy_plane, Nout};
     a.g[0].b = {{(const bf16_t*)w, ldw, Kin, Nout}, w_plane, Nout};
     a.g[0].e = {(bf16_t*)dx, (const bf16_t*)y, y ? act : ACT_NONE, lddx, ldy, dx_plane};
     a.g[0].M = M; a.g[0].N = Kin; a.g[0].K = Nout;
-    if (M <= 32 || small_grid(M, Kin, 1)) launch_gemm<32, 64, 1, 4>(a, 1, M, Kin, Nout, 0, stream);
+    const int big = pda_gemm_large_tiles(M, Kin, 1, 3);
+    if (big == 3) launch_gemm<128, 64, 2, 2, SA, SB, EpiMaskBf16, 32>(a, 1, M, Kin, Nout, 0, stream);
+    else if (big) launch_gemm<128, 128, 2, 2, SA, SB, EpiMaskBf16, 32>(a, 1, M, Kin, Nout, 0, stream);
+    else if (M <= 32 || small_grid(M, Kin, 1)) launch_gemm<32, 64, 1, 4>(a, 1, M, Kin, Nout, 0, stream);
     else launch_gemm<64, 64, 2, 2>(a, 1, M, Kin, Nout, 0, stream);
 }
 

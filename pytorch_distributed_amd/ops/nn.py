@@ -131,6 +131,24 @@ def force_generic_conv1(on):
     L.pda_force_generic_conv1(1 if on else 0)
 
 
+def gemm_tile_mode(mode):
+    """Test / measurement hook of the GEMM entry points' tile choice (csrc/gemm.hip pda_gemm_tile_mode): 0 = by
+    problem size (128 x 128 tiles when they still give every CU a workgroup), 1 = 64 x 64 tiles only, 2 / 3 = the
+    large-tile variants whenever the shape allows."""
+    L = _L()
+    L.pda_gemm_tile_mode.argtypes = [ctypes.c_int]
+    L.pda_gemm_tile_mode.restype = None
+    L.pda_gemm_tile_mode(int(mode))
+
+
+def gemm_large_tiles(M, N, units=1):
+    """True when the slab / split-operand fc forward of this size runs on 128 x 128 tiles (csrc/gemm.hip)."""
+    L = _L()
+    L.pda_gemm_large_tiles.argtypes = [ctypes.c_int] * 4
+    L.pda_gemm_large_tiles.restype = ctypes.c_int
+    return bool(L.pda_gemm_large_tiles(int(M), int(N), int(units), 2))
+
+
 def conv1_specialised(H, W, C, KH, KW, S, O):
     """True when the whole-image conv1 kernels (csrc/nature_conv1.hip) cover this layer.  (FORCE_GENERIC_CONV1: a
     test hook -- tests/test_gpu_gemm.py runs the Nature geometry through the generic implicit-GEMM kernels too.)"""

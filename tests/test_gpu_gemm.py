@@ -74,6 +74,33 @@ def test_linear_fwd_slab_both_block_orders(nn, M, groups, ksplit):
         close(o.sum(0), x @ w.t(), 1e-3, 1e-3)
 
 
+@pytest.fixture
+def tile_mode(nn):
+    """Force a tile variant of the GEMM entry points for one test (csrc/gemm.hip pda_gemm_tile_mode)."""
+    yield nn.gemm_tile_mode
+    nn.gemm_tile_mode(0)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 3136), (300, 200, 328)])
+def test_linear_fwd_slab_and_dgrad_large_tiles(nn, tile_mode, mode, M, N, K):
+    """128 x 128 tiles (k-tile 64 / 32) of fc1's forward and data gradient -- batch 4096's shapes, where mode 0 picks
+    them itself, and a ragged shape (no side a multiple of 128) -- against the 64 x 64 tiles and fp32 torch."""
+    tile_mode(mode)
+    torch.manual_seed(5)
+    xs = [bf(torch.relu(torch.randn(M, K, device="cuda"))) for _ in range(2)]
+    ws = [bf(torch.randn(N, K, device="cuda") / K ** 0.5) for _ in range(2)]
+    outs = [torch.full((1, M, N), 7.0, device="cuda") for _ in range(2)]
+    nn.linear_fwd_slab([x.bfloat16() for x in xs], [w.bfloat16() for w in ws], outs, M, N, K, K, K, N, M * N, K)
+    for x, w, o in zip(xs, ws, outs):
+        close(o[0], x @ w.t(), 1e-3, 1e-3)
+    # data gradient of the same layer: dx[M][K] = (dy[M][N] w[N][K]) * (x > 0)
+    dy = bf(torch.randn(M, N, device="cuda"))
+    dx = torch.full((M, K), 3.0, dtype=torch.bfloat16, device="cuda")
+    nn.linear_dgrad(dy.bfloat16(), ws[0].bfloat16(), xs[0].bfloat16(), dx, M, N, K, N, K, K, K, act=nn.ACT_RELU)
+    close(dx, (dy @ ws[0]) * (xs[0] > 0))
+
+
 def test_linear_fwd_grouped_tanh(nn):
     torch.manual_seed(1)
     M, N, K = 64, 96, 64

@@ -295,6 +295,30 @@ def test_x3_linear_family(nn):
         assert rel(gb2, dq[:, :6].double().sum(0)) < TOL
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 3136), (300, 200, 328)])
+def test_x3_linear_large_tiles(nn, mode, M, N, K):
+    """The 128-row tiles (k-tile 32) of the split-operand fc1 forward / data gradient: batch 4096's shapes, where mode 0
+    picks them, and a ragged shape, against fp64 torch."""
+    nn.gemm_tile_mode(mode)
+    try:
+        torch.manual_seed(6)
+        x = torch.relu(torch.randn(M, K, device="cuda"))
+        ws = [torch.randn(N, K, device="cuda") / K ** 0.5 for _ in range(2)]
+        dy = torch.randn(M, N, device="cuda")
+        xp, wp, dyp = nn.Planes.from_float(x), [nn.Planes.from_float(w) for w in ws], nn.Planes.from_float(dy)
+        slabs = [torch.full((1, M, N), 7.0, device="cuda") for _ in range(2)]
+        nn.x3_linear_fwd([xp, xp], wp, slabs, M, N, K, K, K, N, ksplit=K, slice_stride=M * N)
+        for w, s in zip(ws, slabs):
+            assert rel(s[0], x.double() @ w.double().t()) < TOL
+        dx = nn.Planes(M, K, device="cuda")
+        dx.full.fill_(3.0)
+        nn.x3_linear_dgrad(dyp, wp[0], xp.hi, dx, M, N, K, N, K, K, K, act=nn.ACT_RELU)
+        assert rel(dx.value(), (dy.double() @ ws[0].double()) * (x > 0)) < TOL
+    finally:
+        nn.gemm_tile_mode(0)
+
+
 # ---- the engine at fp32 precision ------------------------------------------------------------------------------
 def _models(A=6, seed=0):
     from pytorch_distributed_amd.models.dqn_cnn_model import DqnCnnModel
