@@ -8,7 +8,11 @@ from inside.  So the question "does whole-step capture work on this node?" is
 answered by a throw-away child process per rank, BEFORE the parent touches the
 GPU: the children form their own process group on a neighbouring port, capture an
 all-reduce on a forked stream, replay it and check the sum.  The parent only
-reads the exit code (with a timeout) and sets PDA_DP_GRAPH=whole|split.
+reads the exit code (with a timeout) and sets PDA_DP_GRAPH=whole, or leaves it at
+auto: the process group's collectives then stay host-driven ("split" graphs), while a
+step whose all-reduce is the peer kernel -- a plain launch -- is still ONE graph.  (A
+failed or timed-out pre-flight used to answer "split", which also split the peer
+kernel's step: half the throughput for a question that never concerned it.)
 
     parent:  mode = preflight.choose_dp_graph_mode()      # before any HIP call
     child:   python -m pytorch_distributed_amd.parallel.preflight
@@ -72,8 +76,9 @@ def _child():
 
 
 def choose_dp_graph_mode(timeout_s=150, backend="nccl", port_offset=23):
-    """Run the child for this rank; returns "whole" or "split".  Call before the parent
-    initialises the GPU.  World size 1 without an explicit request needs no answer."""
+    """Run the child for this rank; returns "whole" (collectives of the process group may be captured) or "auto"
+    (they may not: ops/dqn_program.py:_capture_dp then splits the graph around them, unless the all-reduce is the
+    peer kernel) -- or the knob's value when it was set explicitly.  Call before the parent initialises the GPU."""
     from ..ops.knobs import resolve
     forced = resolve().dp_graph
     forced = None if forced == "auto" else forced
@@ -92,7 +97,7 @@ def choose_dp_graph_mode(timeout_s=150, backend="nccl", port_offset=23):
         proc = subprocess.Popen([sys.executable, "-m", "pytorch_distributed_amd.parallel.preflight"],
                                 env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     except OSError:
-        return "split"
+        return "auto"
     try:
         out, _ = proc.communicate(timeout=timeout_s)
         rc = proc.returncode
@@ -100,7 +105,7 @@ def choose_dp_graph_mode(timeout_s=150, backend="nccl", port_offset=23):
         proc.kill()
         out, _ = proc.communicate()
         rc = -9
-    mode = "whole" if rc == 0 else "split"
+    mode = "whole" if rc == 0 else "auto"
     if rc != 0 and int(os.environ.get("RANK", "0")) == 0:
         tail = out.decode(errors="replace").strip().splitlines()[-3:] if out else []
         print("[preflight] graph-captured collectives unavailable (rc=%s, %.0fs): %s" %
