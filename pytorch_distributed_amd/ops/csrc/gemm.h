@@ -441,6 +441,47 @@ struct EpiMaskBf16 {    // dgrad: out = acc * act'(y[m][n]) -> bf16 ; y is the f
         }
     }
     __device__ __forceinline__ void bias_grad(int, float, int) const {}
+    // columns n .. n + 7 of row m (the staged epilogue, below): one 16-byte load of y and one 16-byte store per
+    // plane when the row pieces are 16-byte aligned, element by element otherwise
+    __device__ __forceinline__ void store8(int m, int n, f32x4 a, f32x4 b, int M, int N) const {
+        if (m >= M || n >= N) return;
+        float g[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        bf16_t* o = out + (long)m * ld + n;
+        const bf16_t* yp = y + (long)m * ldy + n;
+        const bool vec = n + 8 <= N && ((ld | plane) & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                         (act == ACT_NONE || ((ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0));
+        if (vec) {
+            if (act != ACT_NONE) {
+                const uint4 yv = *reinterpret_cast<const uint4*>(yp);
+                const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float yy = bf2f((bf16_t)((yw[e >> 1] >> (16 * (e & 1))) & 0xffffu));
+                    g[e] = (act == ACT_RELU) ? (yy > 0.f ? g[e] : 0.f) : g[e] * (1.f - yy * yy);
+                }
+            }
+            uint32_t hw[4], lw[4];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                hw[e >> 1] = pack2bf(g[e], g[e + 1]);
+                lw[e >> 1] = pack2bf(g[e] - bf2f((bf16_t)(hw[e >> 1] & 0xffffu)), g[e + 1] - bf2f((bf16_t)(hw[e >> 1] >> 16)));
+            }
+            *reinterpret_cast<uint4*>(o) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            if (plane) *reinterpret_cast<uint4*>(o + plane) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (n + e < N) {
+                float gg = g[e];
+                if (act != ACT_NONE) {
+                    const float yy = bf2f(yp[e]);
+                    gg = (act == ACT_RELU) ? (yy > 0.f ? gg : 0.f) : gg * (1.f - yy * yy);
+                }
+                store_split(o + e, plane, gg);
+            }
+        }
+    }
 };
 
 // conv dgrad (gather form): row m of a parity class -> NHWC pixel row; out = acc * act'(y[pixel][n])
@@ -501,6 +542,45 @@ __device__ __forceinline__ EpiWgrad epi_for_slice(const EpiWgrad& e, int by) {
     r.gw += (long)by * e.slice_stride;
     if (r.gb) r.gb += (long)by * e.bslice_stride;
     return r;
+}
+
+// Epilogues with a store8() leave the tile through LDS: the accumulators (MFMA C layout: a lane holds 4 rows of ONE
+// column, so a direct store is 2 bytes per lane in 32-byte runs, and the mask read the same) are parked as fp32
+// [BM][BN + 4] in the k-loop's LDS and come back as 8 consecutive columns per lane -- 16-byte loads of y, 16-byte stores
+// per plane, 128 bytes per row and instruction.  (fc1's data gradient at batch 4096 writes 51-77 MB through this
+// epilogue.)  Used when the parked tile fits the kernel's LDS.
+template <class EP> struct EpiTraits { static constexpr bool kStaged = false; };
+template <> struct EpiTraits<EpiMaskBf16> { static constexpr bool kStaged = true; };
+
+template <int BM, int BN, int WM, int WN, int LDS_BYTES, class EP>
+constexpr bool epi_staged() {
+    return EpiTraits<EP>::kStaged && BN % 8 == 0 && (GEMM_THREADS % (BN / 8)) == 0 &&
+           BM % (GEMM_THREADS / (BN / 8)) == 0 && BM * (BN + 4) * 4 <= LDS_BYTES;
+}
+
+template <int BM, int BN, int WM, int WN, int FM, int FN, class EP>
+__device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[FM][FN], bf16_t* lds, const EP& ep, int m0, int n0,
+                                                int M, int N) {
+    constexpr int P = BN + 4, TPR = BN / 8, RPP = GEMM_THREADS / TPR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    float* st = reinterpret_cast<float*>(lds);
+    __syncthreads();            // every wave is done with the last k-tile
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                st[(wm * (BM / WM) + i * 16 + (lane >> 4) * 4 + r) * P + wn * (BN / WN) + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int r0 = 0; r0 < BM; r0 += RPP) {
+        const int row = r0 + tid / TPR, c = (tid % TPR) * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(st + row * P + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(st + row * P + c + 4);
+        ep.store8(m0 + row, n0 + c, a, b, M, N);
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -709,6 +789,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<SA, SB, EP>& args, int 
 
     // C/D layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
     const EP ep = epi_for_slice(G.e, args.ksplit > 0 ? by : 0);
+    if constexpr (epi_staged<BM, BN, WM, WN, 2 * 2 * (A_ELEMS + B_ELEMS), EP>()) {
+        staged_epilogue<BM, BN, WM, WN, FM, FN>(acc, lds, ep, m0, n0, G.M, G.N);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         int m = m0 + wm * (BM / WM) + i * 16 + (lane >> 4) * 4;
@@ -834,6 +918,10 @@ __device__ __forceinline__ void gemm_body_x3(const GemmArgs<SA, SB, EP>& args, i
     GEMM_RING_LOOP
 
     const EP ep = epi_for_slice(G.e, args.ksplit > 0 ? by : 0);
+    if constexpr (epi_staged<BM, BN, WM, WN, 2 * 2 * BUF, EP>()) {
+        staged_epilogue<BM, BN, WM, WN, FM, FN>(acc, lds, ep, m0, n0, G.M, G.N);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         int m = m0 + wm * (BM / WM) + i * 16 + (lane >> 4) * 4;
