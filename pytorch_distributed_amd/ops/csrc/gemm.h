@@ -16,8 +16,9 @@
 //       fragments come back through ds_read_b64_tr_b16, CDNA4's transposing LDS
 //       read (two 4x16 blocks per fragment), so no scatter of 2-byte LDS writes.
 //
-// Block = 256 threads = 4 wave64s laid out WM x WN over a BM x BN tile, BK = 64
-// (two MFMA k-steps per tile), LDS double-buffered with a register prefetch of the
+// Block = 256 threads = 4 wave64s laid out WM x WN over a BM x BN tile (sides of 32, 64 or 128: the 128-row
+// tiles serve the large-batch fc launches, see gemm.hip), BK = 64 or 32
+// (two / one MFMA k-steps per tile), LDS double-buffered with a register prefetch of the
 // next k-tile, so there is one barrier per k-tile and the global loads of tile t+1
 // fly under the MFMAs of tile t.  LDS tiles are unpadded and XOR-swizzled so that
 // both ds_read_b128 (N mode) and ds_read_b64_tr_b16 (T mode) are bank-conflict free
