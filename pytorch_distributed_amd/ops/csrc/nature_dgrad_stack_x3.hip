@@ -39,15 +39,20 @@ __device__ __forceinline__ void gate_split4(uint2 act, f32x4 v, uint2& hi, uint2
 // W1: the frame patch of the image (bf16, exact) is committed over the dead a2 / da3 grids once conv2^T is done, and
 // the workgroup adds dW1 = da1^T im2col(frames) of its image with both planes of da1 read straight from LDS (as in
 // cnn_dgrad_stack_kernel<., true>): one launch and one round trip of da1 through memory less per step.
-template <bool W1>
+// PAIR: two workgroups per image (small batches: 2 x batch workgroups for 256 CUs; batch 128: 10.25 k -> 10.5 k updates/s).
+// Both run conv3^T, so a pair spends 57.8 k CU-cycles on an image where one workgroup that owns all four parity classes
+// (wave = class, 7 row blocks) spends 33.8 k: large batches, where every CU has images queued anyway, take !PAIR
+// (batch 4096: 403 -> 236 us expected from the phase stamps; the step went from 1.555 to 1.398 ms).
+template <bool W1, bool PAIR = true>
 __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Args a) {
+    static_assert(PAIR || !W1, "the conv1 weight-gradient tail is written for the two-workgroup split");
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-    constexpr int P1 = 400, P2 = 81, P3 = 49, NRB3 = 6, NRB2 = 7;
+    constexpr int P1 = 400, P2 = 81, P3 = 49, NRB3 = 6;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, l15 = lane & 15;
     // two workgroups per image: both run conv3^T (da2 is needed whole), workgroup h = blockIdx.x & 1 then owns the
     // a1 / da1 rows of parity h -- the parity classes (h, 0) and (h, 1) of conv2^T and those pixels' share of dW1
-    const int img = blockIdx.x >> 1, hh = blockIdx.x & 1;
+    const int img = PAIR ? (int)blockIdx.x >> 1 : (int)blockIdx.x, hh = PAIR ? (int)blockIdx.x & 1 : 0;
     constexpr int FH = 84, FW = 84;
     constexpr long frame_bytes = 4L * FH * FW;
     long f0 = 0;
@@ -59,13 +64,16 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     // straight from the transposed shadows the optimizer keeps: 16 bytes per lane and fragment, no staging.  (Transposed
     // through LDS at the start of the launch, as the bf16 kernel does, the four tensors cost 8 barriers and 10 k cycles
     // before the first MFMA.)
-    constexpr int NRB2W = 4;             // conv2^T row blocks per wave: wave = (px, part), part 0 -> blocks 0-3, 1 -> 4-6
-    u32x4 i1[4], i2[3], i3h[2], i3l[2];
-    int in1[4], g1[4], in2[3], in3[2];
+    // conv2^T row blocks per wave.  PAIR: wave = (px, part), part 0 -> blocks 0-3, 1 -> 4-6; else wave = (py, px), all 7
+    constexpr int NRB2W = PAIR ? 4 : 7;
+    constexpr int N1 = PAIR ? 4 : 7;     // 16-byte chunks of a1 per thread: 200 or 400 pixels x 4
+    constexpr int N1_ROWS = PAIR ? 800 : 1600;
+    u32x4 i1[N1], i2[3], i3h[2], i3l[2];
+    int in1[N1], g1[N1], in2[3], in3[2];
     int ld3[NRB3], st3[NRB3], ld2[NRB2W], st2[NRB2W];
     bf16x8 wf3h[18], wf3l[18];      // conv3^T: this wave's 16 input channels; k-step = (tap, o half)
     bf16x8 wf2h[8][2], wf2l[8][2];  // conv2^T: this wave's parity class; (tap a,b ; o half) x 2 channel blocks
-    const int py = hh, px = wave & 1, part = wave >> 1;
+    const int py = PAIR ? hh : wave >> 1, px = wave & 1, part = PAIR ? wave >> 1 : 0;
     const bf16_t* w3src = a.w3t + (long)(wave * 16 + l15) * 64 + g4 * 8;
     const bf16_t* w2src = a.w2t + (long)l15 * 64 + g4 * 8;
 #pragma unroll
@@ -76,10 +84,10 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     }
     STACK_STAMP(a.prof, 0, 1)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {       // chunk t of this workgroup's 200 pixels (rows of parity py) x 4 x 16 bytes
+    for (int i = 0; i < N1; ++i) {      // chunk t of this workgroup's pixels (PAIR: the 200 of row parity hh) x 4 x 16 bytes
         int t = tid + i * 256;
-        t = t < 800 ? t : 0;
-        const int pp = t >> 2, p = (2 * (pp / 20) + py) * 20 + pp % 20;
+        t = t < N1_ROWS ? t : 0;
+        const int pp = t >> 2, p = PAIR ? (2 * (pp / 20) + hh) * 20 + pp % 20 : pp;
         in1[i] = p * D1_CP + (t & 3) * 8;
         g1[i] = p * 4 + (t & 3);
         asm volatile("" : "+v"(in1[i]), "+v"(g1[i]));
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         const u32x4* s3 = reinterpret_cast<const u32x4*>(a.da3 + (long)img * 49 * 64);
         const u32x4* s3l = reinterpret_cast<const u32x4*>(a.da3 + a.da3_plane + (long)img * 49 * 64);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) i1[i] = s1[g1[i]];
+        for (int i = 0; i < N1; ++i) i1[i] = s1[g1[i]];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { int t = tid + i * 256; i2[i] = s2[t < 648 ? t : 0]; }
 #pragma unroll
@@ -144,8 +152,8 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();                    // grids zeroed
 #pragma unroll
-    for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(lds + in1[i]) = i1[i];
-    if (tid < 800 - 768) *reinterpret_cast<u32x4*>(lds + in1[3]) = i1[3];
+    for (int i = 0; i < N1 - 1; ++i) *reinterpret_cast<u32x4*>(lds + in1[i]) = i1[i];
+    if (tid < N1_ROWS - (N1 - 1) * 256) *reinterpret_cast<u32x4*>(lds + in1[N1 - 1]) = i1[N1 - 1];
     *reinterpret_cast<u32x4*>(lds + in2[0]) = i2[0];
     *reinterpret_cast<u32x4*>(lds + in2[1]) = i2[1];
     if (tid < P2 * 8 - 512) *reinterpret_cast<u32x4*>(lds + in2[2]) = i2[2];
@@ -288,8 +296,8 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         uint4* dst = reinterpret_cast<uint4*>(a.da1 + (long)img * P1 * 32);
         uint4* dstl = reinterpret_cast<uint4*>(a.da1 + a.da1_plane + (long)img * P1 * 32);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {           // this workgroup's rows
-            if (i < 3 || tid < 800 - 768) {
+        for (int i = 0; i < N1; ++i) {          // this workgroup's rows
+            if (i < N1 - 1 || tid < N1_ROWS - (N1 - 1) * 256) {
                 dst[g1[i]] = *reinterpret_cast<const uint4*>(lds + in1[i]);
                 dstl[g1[i]] = *reinterpret_cast<const uint4*>(lds + in1[i] + DX_A1L);
             }
@@ -402,10 +410,14 @@ PDA_EXPORT void pda_cnn_dgrad_stack_x3(const void* da3, long da3_plane, const vo
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_x3_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_x3_kernel<false, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (frames)
         hipLaunchKernelGGL(cnn_dgrad_stack_x3_kernel<true>, dim3(2 * batch), dim3(256), (size_t)DX_LDS_ELEMS * 2, stream, a);
+    else if (batch > 256)       // more images than CUs: one workgroup per image (no conv3^T computed twice)
+        hipLaunchKernelGGL((cnn_dgrad_stack_x3_kernel<false, false>), dim3(batch), dim3(256), (size_t)DX_LDS_ELEMS * 2, stream, a);
     else
         hipLaunchKernelGGL(cnn_dgrad_stack_x3_kernel<false>, dim3(2 * batch), dim3(256), (size_t)DX_LDS_ELEMS * 2, stream, a);
 }

@@ -157,10 +157,11 @@ def test_x3_conv_fwd_and_backward(nn, geom):
     assert rel(from_nhwc(dx.value(), batch, H, W, C), xd.grad * (xd.detach() > 0)) < TOL
 
 
-@pytest.mark.parametrize("batch", [7, 130])
+@pytest.mark.parametrize("batch", [7, 130, 300])
 def test_x3_cnn_dgrad_stack(nn, batch):
     """da3 -> da2 -> da1 in one launch on split planes (cnn_dgrad_stack_x3_kernel) against fp64 torch autograd of
-    relu(conv3(relu(conv2(a1)))) with random a1 >= 0 (about half of it exactly 0: the relu' gate of the last stage)."""
+    relu(conv3(relu(conv2(a1)))) with random a1 >= 0 (about half of it exactly 0: the relu' gate of the last stage).
+    Batch 300 takes the one-workgroup-per-image variant (more images than CUs, no conv1 tail)."""
     if not nn.x3_cnn_dgrad_stack_supported(84, 84, 4):
         pytest.skip("fused fp32-precision backward switched off")
     torch.manual_seed(11)
