@@ -43,18 +43,33 @@ __device__ __forceinline__ void gate_split4(uint2 act, f32x4 v, uint2& hi, uint2
 // Both run conv3^T, so a pair spends 57.8 k CU-cycles on an image where one workgroup that owns all four parity classes
 // (wave = class, 7 row blocks) spends 33.8 k: large batches, where every CU has images queued anyway, take !PAIR
 // (batch 4096: 403 -> 236 us expected from the phase stamps; the step went from 1.555 to 1.398 ms).
+// W1 && !PAIR: gridDim.x workgroups walk the batch (image blockIdx.x, + gridDim.x, ...) and add their images' dW1 into
+// ONE slab slice each -- read back at the start of every tail, so the 40 accumulator registers are only live there
+// (kept across the images they spilled: 104 registers, 420 bytes of scratch per lane) -- so large batches get conv1's
+// weight gradient from da1 in LDS too instead of from a launch of its own that reads da1 back from memory.
 template <bool W1, bool PAIR = true>
 __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Args a) {
-    static_assert(PAIR || !W1, "the conv1 weight-gradient tail is written for the two-workgroup split");
+    constexpr bool LOOP = W1 && !PAIR;
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     constexpr int P1 = 400, P2 = 81, P3 = 49, NRB3 = 6;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, l15 = lane & 15;
     // two workgroups per image: both run conv3^T (da2 is needed whole), workgroup h = blockIdx.x & 1 then owns the
     // a1 / da1 rows of parity h -- the parity classes (h, 0) and (h, 1) of conv2^T and those pixels' share of dW1
-    const int img = PAIR ? (int)blockIdx.x >> 1 : (int)blockIdx.x, hh = PAIR ? (int)blockIdx.x & 1 : 0;
+    int img = PAIR ? (int)blockIdx.x >> 1 : (int)blockIdx.x;
+    const int hh = PAIR ? (int)blockIdx.x & 1 : 0;
     constexpr int FH = 84, FW = 84;
     constexpr long frame_bytes = 4L * FH * FW;
+    // (!LOOP: exactly one pass, resolved at compile time)
+#pragma unroll 1
+    for (bool first = true; LOOP ? img < a.batch : first; first = false, img += (int)gridDim.x) {
+    if constexpr (LOOP) __syncthreads();    // the previous image's tail is done with the patch / da1 rows
+    // LOOP: everything below that depends only on the lane is the same for every image; left visible, the compiler
+    // computes all of it in front of the image loop and holds it across (a 64-bit address per weight fragment, the
+    // tail's offsets, ...: 141 spilled registers, 568 bytes of scratch per lane).  Opaque copies keep it in the body.
+    int tid_v = (int)threadIdx.x;
+    if constexpr (LOOP) asm volatile("" : "+v"(tid_v));
+    const int tid = tid_v, lane = tid & 63, g4 = lane >> 4, l15 = lane & 15;
     long f0 = 0;
     if constexpr (W1) f0 = frame_index(a.idx, a.ref, img, a.batch);      // a per-lane load with a counted wait at its use
 
@@ -76,6 +91,11 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     const int py = PAIR ? hh : wave >> 1, px = wave & 1, part = PAIR ? wave >> 1 : 0;
     const bf16_t* w3src = a.w3t + (long)(wave * 16 + l15) * 64 + g4 * 8;
     const bf16_t* w2src = a.w2t + (long)l15 * 64 + g4 * 8;
+    if constexpr (LOOP) {
+        // the fragment addresses below are the same for every image: left visible, they are all hoisted out of the image
+        // loop and held across it (a register pair each: 141 spilled registers)
+        asm volatile("" : "+v"(w3src), "+v"(w2src));
+    }
 #pragma unroll
     for (int ks = 0; ks < 18; ++ks) {       // tap = ks / 2, o half = ks % 2
         const bf16_t* q = w3src + (ks >> 1) * 64 * 64 + (ks & 1) * 32;
@@ -306,8 +326,9 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     STACK_STAMP(a.prof, 0, 7)
     if constexpr (W1) {
         // ---- conv1 weight gradient: dW1[o][(c, ky, kx)] = sum_px da1[px][o] patch[c][4 oy + ky][4 ox + kx];
-        // wave w = kernel channel w; this workgroup's 200 pixels in 7 chunks of 32 (pad pixels read a zeroed strip
-        // behind the patch)
+        // wave w = kernel channel w; this workgroup's 200 (PAIR) / 400 pixels in 7 / 13 chunks of 32 (pad pixels read
+        // a zeroed strip behind the patch)
+        constexpr int NPIX = PAIR ? 200 : 400, NCH = PAIR ? 6 : 12;      // NCH + 1 chunks
         bf16_t* patch = lds + DX_A2H;
         constexpr int ZOFF = DX_A2H + 4 * FH * FW;
         static_assert(ZOFF + 64 <= DX_LDS_ELEMS, "zero strip");
@@ -315,24 +336,43 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         if (tid < 8) *reinterpret_cast<uint4*>(lds + ZOFF + tid * 8) = make_uint4(0, 0, 0, 0);
         __syncthreads();
         const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+        // [32][256] tile <-> slab slice blockIdx.x (kernel layout == PyTorch's (c, ky, kx)); LOOP: the raw sums of the
+        // workgroup's earlier images come back from it, the last image leaves them scaled
+        float* dw = a.gw1 + (long)blockIdx.x * a.ws1;
+        float* db = a.gb1 ? a.gb1 + (long)blockIdx.x * a.bs1 : nullptr;
         f32x4 acc1[2][4], accb1[2];
-        int boff[4];
-        bf16x8 ones;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             accb1[i] = zero4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc1[i][j] = zero4;
         }
+        if constexpr (LOOP) {
+            if (!first) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc1[i][j][r] = dw[(long)(i * 16 + g4 * 4 + r) * 256 + wave * 64 + j * 16 + l15];
+                    if (wave == 0 && l15 == 0 && db) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accb1[i][r] = db[i * 16 + g4 * 4 + r];
+                    }
+                }
+            }
+        }
+        int boff[4];
+        bf16x8 ones;
 #pragma unroll
         for (int j = 0; j < 4; ++j) boff[j] = wave * FH * FW + (2 * j + (tp >> 1)) * FW + 4 * (tp & 1);
 #pragma unroll
         for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
         auto load = [&](bf16x8 (&fa)[4], bf16x8 (&fb)[4], int ch) {
             const int pp0 = ch * 32 + 8 * tg + tq, pp1 = pp0 + 4;
-            const bool in0 = pp0 < 200, in1 = pp1 < 200;
-            const int y0 = in0 ? 2 * (pp0 / 20) + py : 0, x0 = in0 ? pp0 % 20 : 0;
-            const int y1 = in1 ? 2 * (pp1 / 20) + py : 0, x1 = in1 ? pp1 % 20 : 0;
+            const bool in0 = pp0 < NPIX, in1 = pp1 < NPIX;
+            const int y0 = in0 ? (PAIR ? 2 * (pp0 / 20) + hh : pp0 / 20) : 0, x0 = in0 ? pp0 % 20 : 0;
+            const int y1 = in1 ? (PAIR ? 2 * (pp1 / 20) + hh : pp1 / 20) : 0, x1 = in1 ? pp1 % 20 : 0;
             int a0 = (in0 ? (y0 * 20 + x0) * D1_CP : ZOFF) + 4 * tp, a1o = (in1 ? (y1 * 20 + x1) * D1_CP : ZOFF) + 4 * tp;
             int l0 = in0 ? DX_A1L : 0, l1 = in1 ? DX_A1L : 0;
 #pragma unroll
@@ -362,15 +402,14 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
         load(fa0, fb0, 0);
 #pragma unroll 1
-        for (int ch = 0; ch < 6; ch += 2) {         // chunks ch, ch + 1; fragments one chunk ahead
+        for (int ch = 0; ch < NCH; ch += 2) {       // chunks ch, ch + 1; fragments one chunk ahead
             load(fa1, fb1, ch + 1);
             mma(fa0, fb0);
             load(fa0, fb0, ch + 2);
             mma(fa1, fb1);
         }
-        mma(fa0, fb0);                              // chunk 6
-        // [32][256] tile -> slab slice blockIdx.x (kernel layout == PyTorch's (c, ky, kx))
-        float* dw = a.gw1 + (long)blockIdx.x * a.ws1;
+        mma(fa0, fb0);                              // the last chunk
+        const float sc = (!LOOP || img + (int)gridDim.x >= a.batch) ? a.scale1 : 1.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int o = i * 16 + g4 * 4;
@@ -378,22 +417,27 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
             for (int j = 0; j < 4; ++j) {
                 int k = wave * 64 + j * 16 + l15;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dw[(long)(o + r) * 256 + k] = acc1[i][j][r] * a.scale1;
+                for (int r = 0; r < 4; ++r) dw[(long)(o + r) * 256 + k] = acc1[i][j][r] * sc;
             }
-            if (wave == 0 && l15 == 0 && a.gb1) {
+            if (wave == 0 && l15 == 0 && db) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a.gb1[(long)blockIdx.x * a.bs1 + o + r] = accb1[i][r];
+                for (int r = 0; r < 4; ++r) db[o + r] = accb1[i][r];
             }
         }
         STACK_STAMP(a.prof, 0, 8)
     }
+    }   // images of this workgroup
 }
 
 }  // namespace
 
+// conv1 weight-gradient slab slices the launch below writes when it is given the frames: one per workgroup -- two
+// workgroups per image up to 256 images, 256 workgroups walking the batch above
+PDA_EXPORT int pda_cnn_dgrad_stack_x3_slices(int batch) { return batch <= 256 ? 2 * batch : 256; }
+
 // the chain at fp32 precision: da3 / da2 / da1 and the weights as (hi, lo) planes, a2 / a1 hi planes (relu masks)
 // w3t / w2t: the TRANSPOSED weight shadows [(tap, c)][o].  frames != null: the launch also writes conv1's weight
-// gradient, TWO slab slices (ws1 / bs1 floats apart) per image (one per workgroup)
+// gradient, pda_cnn_dgrad_stack_x3_slices(batch) slab slices (ws1 / bs1 floats apart)
 PDA_EXPORT void pda_cnn_dgrad_stack_x3(const void* da3, long da3_plane, const void* a2, const void* a1,
                                        const void* w3t, const void* w2t, long w_plane, void* da2, long da2_plane,
                                        void* da1, long da1_plane, int batch, const void* frames, const void* idx,
@@ -412,9 +456,14 @@ PDA_EXPORT void pda_cnn_dgrad_stack_x3(const void* da3, long da3_plane, const vo
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_x3_kernel<false, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_stack_x3_kernel<true, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (frames)
+    if (frames && batch > 256)  // pda_cnn_dgrad_stack_x3_slices(batch) workgroups walk the batch, one dW1 slab slice each
+        hipLaunchKernelGGL((cnn_dgrad_stack_x3_kernel<true, false>), dim3(pda_cnn_dgrad_stack_x3_slices(batch)), dim3(256),
+                           (size_t)DX_LDS_ELEMS * 2, stream, a);
+    else if (frames)
         hipLaunchKernelGGL(cnn_dgrad_stack_x3_kernel<true>, dim3(2 * batch), dim3(256), (size_t)DX_LDS_ELEMS * 2, stream, a);
     else if (batch > 256)       // more images than CUs: one workgroup per image (no conv3^T computed twice)
         hipLaunchKernelGGL((cnn_dgrad_stack_x3_kernel<false, false>), dim3(batch), dim3(256), (size_t)DX_LDS_ELEMS * 2, stream, a);

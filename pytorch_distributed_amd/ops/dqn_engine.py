@@ -84,7 +84,7 @@ class DqnCnnEngine(object):
         # conv1's weight gradient as a tail of the dgrad stack launch (da1 still in LDS)
         self.fuse_w1 = bool(self.acts.stack_dgrad) and nn.conv1_specialised(g.H, g.W, g.C, 8, 8, 4, 32) and not x3
         # the same for the fp32-precision dgrad stack (two workgroups = two slab slices per image: small batches)
-        self.x3_fuse_w1 = x3 and nn.x3_cnn_dgrad_stack_supported(g.H, g.W, g.C) and self.B <= 256
+        self.x3_fuse_w1 = x3 and nn.x3_cnn_dgrad_stack_supported(g.H, g.W, g.C)
         self._plan_wgrads()
         self._fc_pair = None
         self.idx = torch.zeros(self.B, dtype=torch.int32, device=dev)
@@ -138,7 +138,9 @@ class DqnCnnEngine(object):
                 if self.fuse_w1 and not self.x3:
                     ns = nn.cnn_dgrad_stack_slices(B)   # computed by the dgrad stack launch itself
                 if self.x3_fuse_w1:
-                    ns = 2 * B                          # fp32-precision dgrad stack: one slice per workgroup, two per image
+                    # fp32-precision dgrad stack: one slice per workgroup (two per image up to 256 images; above, 256
+                    # workgroups walk the batch and keep one accumulator each)
+                    ns = nn.x3_cnn_dgrad_stack_slices(B)
             plans.append((li, O, K, ks, ns))
         self.wg_plan = plans
         total = sum(ns * (O * K + O) for _, O, K, _, ns in plans)

@@ -572,12 +572,21 @@ def x3_cnn_dgrad_stack_supported(H, W, C):
     return not FORCE_GENERIC_CONV1 and bool(_L().pda_cnn_dgrad_stack_supported(H, W, C))
 
 
+def x3_cnn_dgrad_stack_slices(batch):
+    """conv1 weight-gradient slab slices x3_cnn_dgrad_stack(..., w1=...) writes: one per workgroup."""
+    L = _L()
+    L.pda_cnn_dgrad_stack_x3_slices.argtypes = [ctypes.c_int]
+    L.pda_cnn_dgrad_stack_x3_slices.restype = ctypes.c_int
+    return int(L.pda_cnn_dgrad_stack_x3_slices(int(batch)))
+
+
 def x3_cnn_dgrad_stack(da3, a2_hi, a1_hi, w3t, w2t, da2, da1, batch, w1=None):
     """da3 -> da2 -> da1 on split planes in one launch (cnn_dgrad_stack_x3_kernel): da* as Planes, the weights as the
     TRANSPOSED split shadows [(tap, c)][o] the optimizer keeps (CnnWeights.wT; both in one shadow buffer: one plane
     offset), a2 / a1 the hi planes of the forward activations.
-    w1 = (frames uint8, idx int32 or None, gw slab [2 * batch][32*256], gb slab [2 * batch][32], scale): the same launch
-    also leaves conv1's weight / bias gradient, one slab slice per workgroup (two workgroups share an image)."""
+    w1 = (frames uint8, idx int32 or None, gw slab [slices][32*256], gb slab [slices][32], scale), slices =
+    x3_cnn_dgrad_stack_slices(batch): the same launch also leaves conv1's weight / bias gradient, one slab slice per
+    workgroup (two workgroups share an image up to 256 images; above, 256 workgroups walk the batch)."""
     assert _plane(w3t) == _plane(w2t)
     frames, idx, gw, gb, scale = w1 if w1 is not None else (None, None, None, None, 1.0)
     (ref,), stride = _windows([frames])

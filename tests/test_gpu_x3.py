@@ -161,7 +161,8 @@ def test_x3_conv_fwd_and_backward(nn, geom):
 def test_x3_cnn_dgrad_stack(nn, batch):
     """da3 -> da2 -> da1 in one launch on split planes (cnn_dgrad_stack_x3_kernel) against fp64 torch autograd of
     relu(conv3(relu(conv2(a1)))) with random a1 >= 0 (about half of it exactly 0: the relu' gate of the last stage).
-    Batch 300 takes the one-workgroup-per-image variant (more images than CUs, no conv1 tail)."""
+    Batch 300 takes the one-workgroup-per-image variants (more images than CUs): one image per workgroup without the
+    conv1 tail, 256 workgroups walking the batch with it."""
     if not nn.x3_cnn_dgrad_stack_supported(84, 84, 4):
         pytest.skip("fused fp32-precision backward switched off")
     torch.manual_seed(11)
@@ -200,8 +201,10 @@ def test_x3_cnn_dgrad_stack(nn, batch):
     # the same launch with conv1's weight gradient as its tail, frames through an index
     mem = torch.randint(0, 256, (40, 4, 84, 84), dtype=torch.uint8, device="cuda")
     idx = torch.randint(0, 40, (batch,), dtype=torch.int32, device="cuda")
-    gw = torch.full((2 * batch, 32 * 256), 7.0, device="cuda")      # one slab slice per workgroup, two per image
-    gb = torch.full((2 * batch, 32), 7.0, device="cuda")
+    ns = nn.x3_cnn_dgrad_stack_slices(batch)        # one slab slice per workgroup: two per image, or 256 walking the batch
+    assert ns == (2 * batch if batch <= 256 else 256)
+    gw = torch.full((ns, 32 * 256), 7.0, device="cuda")
+    gb = torch.full((ns, 32), 7.0, device="cuda")
     da2.full.fill_(9.0)
     da1.full.fill_(9.0)
     nn.x3_cnn_dgrad_stack(planes_nhwc(nn, da3), a2_hi, a1_hi, views[1], views[0], da2, da1, batch,
