@@ -23,6 +23,12 @@ __device__ __forceinline__ void relu_split4(f32x4 v, float s, f32x4 bias, uint2&
     lo = make_uint2(pack2bf(r0, r1), pack2bf(r2, r3));
 }
 
+// MULTI (more images than CUs): gridDim.x workgroups per network walk the batch (image blockIdx.x, + gridDim.x, ...).
+// The layers' weights are still resident only while a layer runs and come from the L2 per image, but conv1's stay staged
+// in an LDS region of their own (2 x 32 x 264 elements behind the activations: 155 KB in all) and the NEXT image's frames
+// are requested when conv3 starts -- an image no longer begins with a cold fetch of its frames and the staging of w1
+// (7.4 k of the 32.8 k cycles of an image, profiles/r2_stack_kernel_phases.txt).
+template <bool MULTI>
 __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     constexpr int C = 4, H = 84, W = 84, KS1 = 8, KS2 = 16, KS3 = 18;
@@ -32,8 +38,10 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
     constexpr int PLANE = FWD_PLANE;
     const int grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, l15 = lane & 15;
-    const int img = blockIdx.x;
+    int img = blockIdx.x;
     bf16_t* patch = lds;
+    // conv1's weights in LDS, [32][256 + 8] rows per plane: in the (still unused) a1 region, or (MULTI) behind everything
+    constexpr int W1P = 264, W1S = MULTI ? 4 * PLANE + 2 * X_A1LO : C * PLANE;
 
     STACK_STAMP(a.prof, 0, 0)
     const long wp = a.w_plane;
@@ -55,6 +63,7 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
         if (a.ref[grp]) f0 = (long)a.ref[grp][f0];
         patch_issue_at<7>(pr, a.frames[grp] + f0 * a.frame_stride, frame_bytes, tid);
     }
+    long f_nxt = MULTI ? frame_index(a.idx[grp], a.ref[grp], img + (int)gridDim.x, a.batch) : 0;
     STACK_STAMP(a.prof, 0, 10)
     // conv2's weights are fetched under conv1's MFMAs, conv3's under conv2's: issued here they would share the L2 -> L1
     // path with the frames and conv1's weights, which the first MFMA waits for (190 KB per workgroup, 256 workgroups
@@ -67,15 +76,7 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
     const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2[grp] + wave * 16 + 4 * g4);
     const f32x4 b3v = *reinterpret_cast<const f32x4*>(a.b3[grp] + wave * 16 + 4 * g4);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    {   // w1 -> [32][256 + 8] rows in the (still unused) a1 region -> fragments: 16 lanes x 16 B cover the 64 banks once
-        constexpr int W1S = C * PLANE, W1P = 264;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int t = tid + i * 256, off = W1S + (t >> 5) * W1P + (t & 31) * 8;
-            *reinterpret_cast<u32x4*>(lds + off) = r1h[i];
-            *reinterpret_cast<u32x4*>(lds + off + 32 * W1P) = r1l[i];
-        }
-        __syncthreads();
+    auto read_w1 = [&]() __attribute__((always_inline)) {      // fragments: 16 lanes x 16 B cover the 64 banks once
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks)
 #pragma unroll
@@ -84,6 +85,18 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
                 wf1h[ks][nb] = *reinterpret_cast<const bf16x8*>(q);
                 wf1l[ks][nb] = *reinterpret_cast<const bf16x8*>(q + 32 * W1P);
             }
+    };
+    {   // w1 -> [32][256 + 8] rows in LDS -> fragments (MULTI: per image, inside the loop)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = tid + i * 256, off = W1S + (t >> 5) * W1P + (t & 31) * 8;
+            *reinterpret_cast<u32x4*>(lds + off) = r1h[i];
+            *reinterpret_cast<u32x4*>(lds + off + 32 * W1P) = r1l[i];
+        }
+        if constexpr (!MULTI) {
+            __syncthreads();
+            read_w1();
+        }
     }
     STACK_STAMP(a.prof, 0, 13)
     int ld1[7], st1[7], co1[7], ld2[NRB2], st2[NRB2], co2[3], ld3[NRB3], st3[NRB3];
@@ -125,9 +138,19 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
         asm volatile("" : "+v"(ld3[rb]), "+v"(st3[rb]));
     }
 
+    // (!MULTI: exactly one pass, resolved at compile time)
+#pragma unroll 1
+    for (bool first = true; MULTI ? img < a.batch : first; first = false, img += (int)gridDim.x) {
     STACK_STAMP(a.prof, 0, 1)
+    if constexpr (MULTI) {
+        __syncthreads();        // the previous image's conv3 is done with a2 (which lies over the patch)
+        // the weight-fragment addresses are the same for every image: left visible they are all computed in front of
+        // the image loop and held across it, a register pair each (nature_dgrad_stack_x3.hip: 141 spilled registers)
+        asm volatile("" : "+v"(w2src), "+v"(w3src));
+    }
     patch_commit<7, H * W / 16, PLANE - H * W>(pr, frame_bytes, patch, tid);
     __syncthreads();
+    if constexpr (MULTI) read_w1();
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
         pin_agpr(wf1h[ks][0]); pin_agpr(wf1h[ks][1]); pin_agpr(wf1l[ks][0]); pin_agpr(wf1l[ks][1]);
@@ -263,6 +286,10 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
     __syncthreads();                    // a2 complete
 #pragma unroll
     for (int ks = 0; ks < KS3; ++ks) { pin_agpr(wf3h[ks]); pin_agpr(wf3l[ks]); }
+    if constexpr (MULTI) {      // the next image's frames fly under conv3 (past the end: frame_index clamps to image 0)
+        patch_issue_at<7>(pr, a.frames[grp] + f_nxt * a.frame_stride, frame_bytes, tid);
+        f_nxt = frame_index(a.idx[grp], a.ref[grp], img + 2 * (int)gridDim.x, a.batch);
+    }
     STACK_STAMP(a.prof, 0, 8)
     // ---- conv3 -> global a3 hi / lo; unit = 9 of the 18 k-steps of a row block
     {
@@ -321,6 +348,7 @@ __global__ __launch_bounds__(256) void cnn_fwd_stack_x3_kernel(FwdStackArgs a) {
         if ((NRB3 - 1) & 1) store3(cb, NRB3 - 1); else store3(ca, NRB3 - 1);
     }
     STACK_STAMP(a.prof, 0, 9)
+    }   // images of this workgroup
 }
 
 }  // namespace
@@ -348,9 +376,18 @@ PDA_EXPORT void pda_cnn_fwd_stack_x3(const void* const* frames, const void* cons
     size_t lds = ((size_t)4 * FWD_PLANE + 2 * (size_t)X_A1LO) * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_fwd_stack_x3_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_fwd_stack_x3_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_fwd_stack_x3_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(cnn_fwd_stack_x3_kernel, dim3(batch, ngroups), dim3(256), lds, stream, a);
+    const int per_group = 256 / (ngroups > 0 ? ngroups : 1);      // one workgroup per CU over all networks
+    if (per_group >= 1 && batch >= 4 * per_group) {                 // >= 4 images per workgroup: walk the batch
+        const size_t lds_multi = lds + (size_t)2 * 32 * 264 * 2;     // + conv1's weights, both planes
+        static_assert(((size_t)4 * FWD_PLANE + 2 * (size_t)X_A1LO) * 2 + 2 * 32 * 264 * 2 <= 160 * 1024, "LDS budget");
+        hipLaunchKernelGGL(cnn_fwd_stack_x3_kernel<true>, dim3(per_group, ngroups), dim3(256), lds_multi, stream, a);
+        return;
+    }
+    hipLaunchKernelGGL(cnn_fwd_stack_x3_kernel<false>, dim3(batch, ngroups), dim3(256), lds, stream, a);
 }

@@ -76,10 +76,11 @@ class _View(object):
         return self.hi.data_ptr()
 
 
-@pytest.mark.parametrize("batch,use_idx", [(9, True), (3, False)])
+@pytest.mark.parametrize("batch,use_idx", [(9, True), (3, False), (520, True)])
 def test_x3_cnn_fwd_stack(nn, batch, use_idx):
     """conv1 -> conv2 -> conv3 in one launch on split planes (cnn_fwd_stack_x3_kernel), two networks, the second
-    without kept a1 / a2, against fp64 torch."""
+    without kept a1 / a2, against fp64 torch.  520 images per network: 128 workgroups per network walk the batch
+    (four or five images each, the next image's frames requested under conv3)."""
     if not nn.x3_cnn_fwd_stack_supported(84, 84, 4):
         pytest.skip("fused fp32-precision forward switched off")
     torch.manual_seed(5)
