@@ -280,6 +280,11 @@ def timed_windows(core, comm, steps, min_time, max_windows, sync, reduce_max):
 
 
 def run_rank(a):
+    # stdout carries ONE line, the JSON: libraries write there too (RCCL prints its version banner on the first
+    # communicator), so file descriptor 1 points at stderr from here on and the result goes out through a copy
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     if os.environ.get("PDA_BENCH_FAULTHANDLER"):     # debugging aid: dump every thread's stack if we stall
         import faulthandler
@@ -533,7 +538,9 @@ def run_rank(a):
                                 "b4096_value": "config 5 learner: batch 4096, prioritized replay, fp32-class engine, "
                                                "updates/s (x 4096 = samples/s)"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 def main(argv=None):
