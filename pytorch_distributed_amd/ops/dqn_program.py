@@ -171,7 +171,9 @@ class DqnStepProgram(object):
                 self.ar_tail.all_reduce_sum_(self.tail)     # (peer kernel: bf16 wire conversion happens in it)
             mark("tail1", self.comm_stream)
             self.tail_done.record(self.comm_stream)
-        b()
+        b()     # (incl. the conv bucket's slab sums; measured and removed: that launch on the comm stream, in front of
+        # the bucket's all-reduce and beside the fc tail's optimizer update -- 9.0 k vs 9.9 k updates/s in the one-rank
+        # rehearsal: it competes with the optimizer for bandwidth and delays the all-reduce the second update waits for)
         self.conv_done.record(cur)
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(self.conv_done)
