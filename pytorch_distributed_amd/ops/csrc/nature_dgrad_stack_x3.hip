@@ -43,10 +43,9 @@ __device__ __forceinline__ void gate_split4(uint2 act, f32x4 v, uint2& hi, uint2
 // Both run conv3^T, so a pair spends 57.8 k CU-cycles on an image where one workgroup that owns all four parity classes
 // (wave = class, 7 row blocks) spends 33.8 k: large batches, where every CU has images queued anyway, take !PAIR
 // (batch 4096: 403 -> 236 us expected from the phase stamps; the step went from 1.555 to 1.398 ms).
-// W1 && !PAIR: gridDim.x workgroups walk the batch (image blockIdx.x, + gridDim.x, ...) and add their images' dW1 into
-// ONE slab slice each -- read back at the start of every tail, so the 40 accumulator registers are only live there
-// (kept across the images they spilled: 104 registers, 420 bytes of scratch per lane) -- so large batches get conv1's
-// weight gradient from da1 in LDS too instead of from a launch of its own that reads da1 back from memory.
+// W1 && !PAIR: gridDim.x workgroups walk the batch (image blockIdx.x, + gridDim.x, ...) and keep ONE dW1 accumulator
+// each across their images -- one slab slice per workgroup whatever the batch, so large batches get conv1's weight
+// gradient from da1 in LDS too instead of from a launch of its own that reads da1 back from memory.
 template <bool W1, bool PAIR = true>
 __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Args a) {
     constexpr bool LOOP = W1 && !PAIR;
@@ -60,6 +59,15 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     const int hh = PAIR ? (int)blockIdx.x & 1 : 0;
     constexpr int FH = 84, FW = 84;
     constexpr long frame_bytes = 4L * FH * FW;
+    f32x4 acc1[2][4], accb1[2];         // dW1 / db1 (W1): of this image, or (LOOP) of all of this workgroup's images
+    if constexpr (W1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            accb1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
     // (!LOOP: exactly one pass, resolved at compile time)
 #pragma unroll 1
     for (bool first = true; LOOP ? img < a.batch : first; first = false, img += (int)gridDim.x) {
@@ -338,30 +346,6 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
         // [32][256] tile <-> slab slice blockIdx.x (kernel layout == PyTorch's (c, ky, kx)); LOOP: the raw sums of the
         // workgroup's earlier images come back from it, the last image leaves them scaled
-        float* dw = a.gw1 + (long)blockIdx.x * a.ws1;
-        float* db = a.gb1 ? a.gb1 + (long)blockIdx.x * a.bs1 : nullptr;
-        f32x4 acc1[2][4], accb1[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            accb1[i] = zero4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc1[i][j] = zero4;
-        }
-        if constexpr (LOOP) {
-            if (!first) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc1[i][j][r] = dw[(long)(i * 16 + g4 * 4 + r) * 256 + wave * 64 + j * 16 + l15];
-                    if (wave == 0 && l15 == 0 && db) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) accb1[i][r] = db[i * 16 + g4 * 4 + r];
-                    }
-                }
-            }
-        }
         int boff[4];
         bf16x8 ones;
 #pragma unroll
@@ -409,7 +393,13 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
             mma(fa1, fb1);
         }
         mma(fa0, fb0);                              // the last chunk
-        const float sc = (!LOOP || img + (int)gridDim.x >= a.batch) ? a.scale1 : 1.f;
+        STACK_STAMP(a.prof, 0, 8)
+    }
+    }   // images of this workgroup
+    if constexpr (W1) {
+        // [32][256] tile -> slab slice blockIdx.x (kernel layout == PyTorch's (c, ky, kx))
+        const int lane = (int)threadIdx.x & 63, g4 = lane >> 4, l15 = lane & 15;
+        float* dw = a.gw1 + (long)blockIdx.x * a.ws1;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int o = i * 16 + g4 * 4;
@@ -417,16 +407,14 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
             for (int j = 0; j < 4; ++j) {
                 int k = wave * 64 + j * 16 + l15;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dw[(long)(o + r) * 256 + k] = acc1[i][j][r] * sc;
+                for (int r = 0; r < 4; ++r) dw[(long)(o + r) * 256 + k] = acc1[i][j][r] * a.scale1;
             }
-            if (wave == 0 && l15 == 0 && db) {
+            if (wave == 0 && l15 == 0 && a.gb1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) db[o + r] = accb1[i][r];
+                for (int r = 0; r < 4; ++r) a.gb1[(long)blockIdx.x * a.bs1 + o + r] = accb1[i][r];
             }
         }
-        STACK_STAMP(a.prof, 0, 8)
     }
-    }   // images of this workgroup
 }
 
 }  // namespace
