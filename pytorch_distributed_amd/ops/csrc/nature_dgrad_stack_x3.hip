@@ -68,6 +68,24 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
             for (int j = 0; j < 4; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
+    bf16x8 wf3h[18], wf3l[18];      // conv3^T: this wave's 16 input channels; k-step = (tap, o half)
+    // fragments [k0, k1) of conv3's weights (tap = ks / 2, o half = ks % 2), both planes, from the transposed shadow.
+    // LOOP: an image's prologue is mostly the wait for these 147 KB per workgroup (a CU pulls ~20 B/clk through its L1:
+    // 6.9 k of the 46.5 k cycles of an image), so the NEXT image's are requested under the conv1 weight-gradient tail
+    auto issue_w3 = [&](const bf16_t* w3src, int k0, int k1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) {
+            if (ks >= k0 && ks < k1) {
+                const bf16_t* q = w3src + (ks >> 1) * 64 * 64 + (ks & 1) * 32;
+                wf3h[ks] = *reinterpret_cast<const bf16x8*>(q);
+                wf3l[ks] = *reinterpret_cast<const bf16x8*>(q + a.w_plane);
+            }
+        }
+    };
+    if constexpr (LOOP) {
+        const int lane0 = (int)threadIdx.x & 63;
+        issue_w3(a.w3t + (long)(wave * 16 + (lane0 & 15)) * 64 + (lane0 >> 4) * 8, 0, 18);
+    }
     // (!LOOP: exactly one pass, resolved at compile time)
 #pragma unroll 1
     for (bool first = true; LOOP ? img < a.batch : first; first = false, img += (int)gridDim.x) {
@@ -94,7 +112,6 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     u32x4 i1[N1], i2[3], i3h[2], i3l[2];
     int in1[N1], g1[N1], in2[3], in3[2];
     int ld3[NRB3], st3[NRB3], ld2[NRB2W], st2[NRB2W];
-    bf16x8 wf3h[18], wf3l[18];      // conv3^T: this wave's 16 input channels; k-step = (tap, o half)
     bf16x8 wf2h[8][2], wf2l[8][2];  // conv2^T: this wave's parity class; (tap a,b ; o half) x 2 channel blocks
     const int py = PAIR ? hh : wave >> 1, px = wave & 1, part = PAIR ? wave >> 1 : 0;
     const bf16_t* w3src = a.w3t + (long)(wave * 16 + l15) * 64 + g4 * 8;
@@ -104,12 +121,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         // loop and held across it (a register pair each: 141 spilled registers)
         asm volatile("" : "+v"(w3src), "+v"(w2src));
     }
-#pragma unroll
-    for (int ks = 0; ks < 18; ++ks) {       // tap = ks / 2, o half = ks % 2
-        const bf16_t* q = w3src + (ks >> 1) * 64 * 64 + (ks & 1) * 32;
-        wf3h[ks] = *reinterpret_cast<const bf16x8*>(q);
-        wf3l[ks] = *reinterpret_cast<const bf16x8*>(q + a.w_plane);
-    }
+    if constexpr (!LOOP) issue_w3(w3src, 0, 18);       // (LOOP: requested in front of the loop / under the previous tail)
     STACK_STAMP(a.prof, 0, 1)
 #pragma unroll
     for (int i = 0; i < N1; ++i) {      // chunk t of this workgroup's pixels (PAIR: the 200 of row parity hh) x 4 x 16 bytes
@@ -385,12 +397,25 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         };
         bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
         load(fa0, fb0, 0);
+        if constexpr (LOOP) {
+            // unrolled: the next image's conv3 weight fragments, three per pair of chunks, ride under the MFMAs
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch += 2) {
+                load(fa1, fb1, ch + 1);
+                mma(fa0, fb0);
+                issue_w3(w3src, 3 * (ch / 2), 3 * (ch / 2) + 3);
+                load(fa0, fb0, ch + 2);
+                mma(fa1, fb1);
+            }
+            static_assert(3 * (NCH / 2) == 18, "all 18 fragment pairs are requested by the tail");
+        } else {
 #pragma unroll 1
-        for (int ch = 0; ch < NCH; ch += 2) {       // chunks ch, ch + 1; fragments one chunk ahead
-            load(fa1, fb1, ch + 1);
-            mma(fa0, fb0);
-            load(fa0, fb0, ch + 2);
-            mma(fa1, fb1);
+            for (int ch = 0; ch < NCH; ch += 2) {   // chunks ch, ch + 1; fragments one chunk ahead
+                load(fa1, fb1, ch + 1);
+                mma(fa0, fb0);
+                load(fa0, fb0, ch + 2);
+                mma(fa1, fb1);
+            }
         }
         mma(fa0, fb0);                              // the last chunk
         STACK_STAMP(a.prof, 0, 8)
