@@ -82,9 +82,30 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
             }
         }
     };
+    // this image's inputs (a1 / a2: hi planes only; da3: both): PAIR the 200 a1 pixels of row parity hh, else all 400.
+    // LOOP: the next image's are requested under the tail as well
+    constexpr int N1 = PAIR ? 4 : 7;     // 16-byte chunks of a1 per thread: 200 or 400 pixels x 4
+    constexpr int N1_ROWS = PAIR ? 800 : 1600;
+    u32x4 i1[N1], i2[3], i3h[2], i3l[2];
+    auto issue_inputs = [&](int im, int tid_, const int (&g1_)[N1]) __attribute__((always_inline)) {
+        const u32x4* s1 = reinterpret_cast<const u32x4*>(a.a1 + (long)im * 400 * 32);
+        const u32x4* s2 = reinterpret_cast<const u32x4*>(a.a2 + (long)im * 81 * 64);
+        const u32x4* s3 = reinterpret_cast<const u32x4*>(a.da3 + (long)im * 49 * 64);
+        const u32x4* s3l = reinterpret_cast<const u32x4*>(a.da3 + a.da3_plane + (long)im * 49 * 64);
+#pragma unroll
+        for (int i = 0; i < N1; ++i) i1[i] = s1[g1_[i]];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { int t = tid_ + i * 256; i2[i] = s2[t < 648 ? t : 0]; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { int t = tid_ + i * 256; i3h[i] = s3[t < 392 ? t : 0]; i3l[i] = s3l[t < 392 ? t : 0]; }
+    };
     if constexpr (LOOP) {
-        const int lane0 = (int)threadIdx.x & 63;
+        const int tid0 = (int)threadIdx.x, lane0 = tid0 & 63;
         issue_w3(a.w3t + (long)(wave * 16 + (lane0 & 15)) * 64 + (lane0 >> 4) * 8, 0, 18);
+        int g0[N1];
+#pragma unroll
+        for (int i = 0; i < N1; ++i) { int t = tid0 + i * 256; g0[i] = t < N1_ROWS ? t : 0; }
+        issue_inputs(img, tid0, g0);
     }
     // (!LOOP: exactly one pass, resolved at compile time)
 #pragma unroll 1
@@ -107,9 +128,6 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     // before the first MFMA.)
     // conv2^T row blocks per wave.  PAIR: wave = (px, part), part 0 -> blocks 0-3, 1 -> 4-6; else wave = (py, px), all 7
     constexpr int NRB2W = PAIR ? 4 : 7;
-    constexpr int N1 = PAIR ? 4 : 7;     // 16-byte chunks of a1 per thread: 200 or 400 pixels x 4
-    constexpr int N1_ROWS = PAIR ? 800 : 1600;
-    u32x4 i1[N1], i2[3], i3h[2], i3l[2];
     int in1[N1], g1[N1], in2[3], in3[2];
     int ld3[NRB3], st3[NRB3], ld2[NRB2W], st2[NRB2W];
     bf16x8 wf2h[8][2], wf2l[8][2];  // conv2^T: this wave's parity class; (tap a,b ; o half) x 2 channel blocks
@@ -132,18 +150,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         g1[i] = p * 4 + (t & 3);
         asm volatile("" : "+v"(in1[i]), "+v"(g1[i]));
     }
-    {
-        const u32x4* s1 = reinterpret_cast<const u32x4*>(a.a1 + (long)img * 400 * 32);
-        const u32x4* s2 = reinterpret_cast<const u32x4*>(a.a2 + (long)img * 81 * 64);
-        const u32x4* s3 = reinterpret_cast<const u32x4*>(a.da3 + (long)img * 49 * 64);
-        const u32x4* s3l = reinterpret_cast<const u32x4*>(a.da3 + a.da3_plane + (long)img * 49 * 64);
-#pragma unroll
-        for (int i = 0; i < N1; ++i) i1[i] = s1[g1[i]];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { int t = tid + i * 256; i2[i] = s2[t < 648 ? t : 0]; }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { int t = tid + i * 256; i3h[i] = s3[t < 392 ? t : 0]; i3l[i] = s3l[t < 392 ? t : 0]; }
-    }
+    if constexpr (!LOOP) issue_inputs(img, tid, g1);       // (LOOP: requested in front of the loop / under the previous tail)
     // fragment (t, nb) of conv2^T: t = (a * 2 + b) * 2 + o half, tap = (py + 2a) * 4 + px + 2b, channels 16 nb + l15
     auto w2_frag = [&](int t, int nb, long plane) {
         const int ta = t >> 2, tb = (t >> 1) & 1, half = t & 1;
@@ -408,6 +415,8 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
                 mma(fa1, fb1);
             }
             static_assert(3 * (NCH / 2) == 18, "all 18 fragment pairs are requested by the tail");
+            const int nxt = img + (int)gridDim.x;
+            issue_inputs(nxt < a.batch ? nxt : img, tid, g1);     // (past the end: this image's again, never used)
         } else {
 #pragma unroll 1
             for (int ch = 0; ch < NCH; ch += 2) {   // chunks ch, ch + 1; fragments one chunk ahead

@@ -158,12 +158,13 @@ def test_x3_conv_fwd_and_backward(nn, geom):
     assert rel(from_nhwc(dx.value(), batch, H, W, C), xd.grad * (xd.detach() > 0)) < TOL
 
 
-@pytest.mark.parametrize("batch", [7, 130, 300])
+@pytest.mark.parametrize("batch", [7, 130, 300, 1100])
 def test_x3_cnn_dgrad_stack(nn, batch):
     """da3 -> da2 -> da1 in one launch on split planes (cnn_dgrad_stack_x3_kernel) against fp64 torch autograd of
     relu(conv3(relu(conv2(a1)))) with random a1 >= 0 (about half of it exactly 0: the relu' gate of the last stage).
-    Batch 300 takes the one-workgroup-per-image variants (more images than CUs): one image per workgroup without the
-    conv1 tail, 256 workgroups walking the batch with it."""
+    Batches 300 / 1100 take the one-workgroup-per-image variants (more images than CUs): one image per workgroup without
+    the conv1 tail, 256 workgroups walking the batch with it (one or two / four or five images each, the next image's
+    inputs and conv3 weights requested under the tail)."""
     if not nn.x3_cnn_dgrad_stack_supported(84, 84, 4):
         pytest.skip("fused fp32-precision backward switched off")
     torch.manual_seed(11)
