@@ -107,6 +107,11 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         for (int i = 0; i < N1; ++i) { int t = tid0 + i * 256; g0[i] = t < N1_ROWS ? t : 0; }
         issue_inputs(img, tid0, g0);
     }
+    // per-lane LDS offsets of the grids: the same for every image, computed by the first pass only (in1 / g1, which cost
+    // no division when a workgroup owns whole images, per image: all of them held across the loop spill 5 registers)
+    constexpr int NRB2W = PAIR ? 4 : 7;  // conv2^T row blocks per wave.  PAIR: wave = (px, part), part 0 -> blocks 0-3, 1 -> 4-6; else wave = (py, px), all 7
+    int in1[N1], g1[N1], in2[3], in3[2];
+    int ld3[NRB3], st3[NRB3], ld2[NRB2W], st2[NRB2W];
     // (!LOOP: exactly one pass, resolved at compile time)
 #pragma unroll 1
     for (bool first = true; LOOP ? img < a.batch : first; first = false, img += (int)gridDim.x) {
@@ -126,10 +131,6 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     // straight from the transposed shadows the optimizer keeps: 16 bytes per lane and fragment, no staging.  (Transposed
     // through LDS at the start of the launch, as the bf16 kernel does, the four tensors cost 8 barriers and 10 k cycles
     // before the first MFMA.)
-    // conv2^T row blocks per wave.  PAIR: wave = (px, part), part 0 -> blocks 0-3, 1 -> 4-6; else wave = (py, px), all 7
-    constexpr int NRB2W = PAIR ? 4 : 7;
-    int in1[N1], g1[N1], in2[3], in3[2];
-    int ld3[NRB3], st3[NRB3], ld2[NRB2W], st2[NRB2W];
     bf16x8 wf2h[8][2], wf2l[8][2];  // conv2^T: this wave's parity class; (tap a,b ; o half) x 2 channel blocks
     const int py = PAIR ? hh : wave >> 1, px = wave & 1, part = PAIR ? wave >> 1 : 0;
     const bf16_t* w3src = a.w3t + (long)(wave * 16 + l15) * 64 + g4 * 8;
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
     for (int t = tid; t < (DX_LDS_ELEMS - DX_A2H) / 8; t += 256)
         *reinterpret_cast<uint4*>(lds + DX_A2H + t * 8) = make_uint4(0, 0, 0, 0);
 
+    if (!LOOP || first) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         int t = tid + i * 256;
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(256) void cnn_dgrad_stack_x3_kernel(DgradStackX3Arg
         ld2[rb] = DX_A2H + (iy2 + 1) * D2_RP + (ix2 + 1) * D2_CP + g4 * 8;
         st2[rb] = ((2 * iy2 + py) * 20 + 2 * ix2 + px) * D1_CP + 4 * g4;
         asm volatile("" : "+v"(ld2[rb]), "+v"(st2[rb]));
+    }
     }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();                    // grids zeroed
