@@ -43,6 +43,11 @@ __device__ __forceinline__ void gate_split4(uint2 act, f32x4 v, uint2& hi, uint2
 // Both run conv3^T, so a pair spends 57.8 k CU-cycles on an image where one workgroup that owns all four parity classes
 // (wave = class, 7 row blocks) spends 33.8 k: large batches, where every CU has images queued anyway, take !PAIR
 // (batch 4096: 403 -> 236 us expected from the phase stamps; the step went from 1.555 to 1.398 ms).
+// (Measured and not kept for PAIR: workgroup h owning a1 rows [10 h, 10 h + 10) instead of a row parity, so that it needs
+// only da2 rows 0-4 or 4-8 -- three conv3^T row blocks instead of six.  The phase went from 8.6 k to 7.3 k cycles, not to
+// half: each wave then owns a parity class of its own and the workgroup pulls ALL of conv2's weights under conv3^T
+// (131 KB instead of 65 KB; ~20 B/clk per CU), and the kernel as a whole stayed at 28.7 k cycles.  It is the 212 KB of
+// split weights per workgroup, not the MFMAs, that bound this kernel at batch 128.)
 // W1 && !PAIR: gridDim.x workgroups walk the batch (image blockIdx.x, + gridDim.x, ...) and keep ONE dW1 accumulator
 // each across their images -- one slab slice per workgroup whatever the batch, so large batches get conv1's weight
 // gradient from da1 in LDS too instead of from a launch of its own that reads da1 back from memory.
